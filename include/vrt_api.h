@@ -1,0 +1,155 @@
+/* vrt_api.h -- C ABI of libvrt_hip.so, the MI355X (gfx950) replacement for the reference's
+ * renderer/{pathtracer,raytracer,bsdf,atmos,reservoir,voxel_world}.py.
+ *
+ * The reference (taichi-dev/voxel-rt2) has no FFI: its seam is the Python object
+ * `Renderer` that scene.py drives.  Every entry point below names the
+ * reference interface it replaces as /root/reference-relative file:line.  The Python facade
+ * voxel_rt2_amd/renderer.py binds these with ctypes and re-exposes the reference's method names.
+ *
+ * Conventions: single host thread per context; every int-returning function gives 0 or a
+ * negative VRT_E_* code and vrt_last_error() a thread-local message; the library owns all
+ * device memory; host pointers are borrowed for the duration of the call; work is queued on the
+ * context's own HIP stream and is asynchronous until a fetch / sync / get_stats call.
+ * There is NO CPU backend: vrt_create fails if no gfx950 device is usable.
+ *
+ * Layouts: images are row-major [row v][column u], v = 0 at the bottom like the reference's
+ * (u, v) field indices.  Voxel arrays are [x+64][y+64][z+64] (C order), the index space of
+ * voxel_world.py:14-18.  Matrices are row-major 4x4 in mathematical convention (element
+ * [row*4+col]); the facade has already transposed the glm-ordered arrays the reference receives
+ * (pathtracer.py:266-268, 278-280) and supplies the inverses.
+ */
+#ifndef VRT_API_H
+#define VRT_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vrt_ctx vrt_ctx;
+
+enum {
+    VRT_OK = 0,
+    VRT_E_INVALID = -1,   /* bad argument / unsupported configuration */
+    VRT_E_DEVICE = -2,    /* HIP error or no gfx950 device */
+    VRT_E_STATE = -3      /* call out of order (e.g. accumulate before prepare) */
+};
+
+/* Renderer.__init__(dx, image_res, up, voxel_edges, exposure): pathtracer.py:28-136, plus the
+ * module constants USE_RESTIR_PT / MAX_RAY_DEPTH (pathtracer.py:15-17) and the skybox size
+ * (atmos.py:66-67) made into parameters. */
+typedef struct vrt_config {
+    int32_t width, height;        /* image_res */
+    int32_t grid_res;             /* voxel_grid_res, pathtracer.py:83 -- must be 128 */
+    float dx;                     /* voxel size in world units (scene.py:11: 1/64) */
+    float voxel_edges;            /* voxel_world.py:25 */
+    float exposure;               /* pathtracer.py:58 */
+    int32_t max_depth;            /* MAX_RAY_DEPTH, 1..64 */
+    int32_t use_restir;           /* USE_RESTIR_PT */
+    uint32_t seed;                /* seed of the per-pixel random streams (replaces ti.random) */
+    int32_t sky_res;              /* skybox edge length, 3840 in the reference; 0 = no sky tables */
+    int32_t device;               /* HIP device ordinal */
+    int32_t row_begin, row_end;   /* rows [row_begin,row_end) this context produces; 0,0 = all.
+                                     Row-tile sharding across GPUs (one context per process). */
+} vrt_config;
+
+/* the scalar fields scene.py pokes with [None] (scene.py:148-169) and
+ * Renderer.set_directional_light (pathtracer.py:139-144) */
+typedef struct vrt_scene_params {
+    float floor_height;
+    float floor_color[3];
+    int32_t floor_material;
+    float background_color[3];
+    float light_direction[3];     /* normalised */
+    float light_cos_theta_max;    /* cos(cone_angle / 2) */
+    float light_color[3];
+    float light_weight;           /* 3.0 once set_directional_light ran (pathtracer.py:144) */
+    int32_t use_physical_sky;
+    int32_t use_clouds;
+} vrt_scene_params;
+
+/* set_camera_pos / set_proj_mat / set_view_mat / set_camera_is_moving / set_render_scale /
+ * set_max_samples: pathtracer.py:146-150, 246-281, 1306-1307 */
+typedef struct vrt_camera {
+    float view[16], proj[16], view_inv[16], proj_inv[16];
+    float pos[3];
+    uint32_t jitter_index;        /* how many times set_proj_mat ran: selects the TAA jitter draw
+                                     (pathtracer.py:264-265) from random stream 3 */
+    int32_t camera_is_moving;
+    float render_scale;
+    float max_accum_frames;
+} vrt_camera;
+
+typedef struct vrt_stats {
+    uint64_t path_samples;        /* pixels x accumulate passes since creation */
+    uint64_t rays, dda_iters, occupancy_queries, closest_hits, sky_lookups; /* instrumented build only, else 0 */
+    double render_ms, temporal_ms, gris_ms;  /* summed device time of the kernels (hipEvent) */
+    uint32_t render_launches, temporal_launches, gris_launches;
+    uint32_t pad;
+} vrt_stats;
+
+/* buffers readable through vrt_fetch_buffer (tests and the multi-GPU gather) */
+enum {
+    VRT_BUF_GBUF_DEPTH = 1,       /* f32  [H][W]      gbuff_depth            pathtracer.py:114 */
+    VRT_BUF_GBUF_NORMAL = 2,      /* f16x2[H][W]      gbuff_normals          :113 */
+    VRT_BUF_GBUF_POSITION = 3,    /* f32x3[H][W]      gbuff_position         :116 */
+    VRT_BUF_GBUF_MAT = 4,         /* u32  [H][W]      gbuff_mat_id           :112 */
+    VRT_BUF_GBUF_REFL_DEPTH = 5,  /* f32  [H][W]      gbuff_depth_reflection :115 */
+    VRT_BUF_HISTORY_DIFFUSE = 6,  /* f32x4[H][W]      history_buffer[...,0]  :43 */
+    VRT_BUF_HISTORY_SPECULAR = 7, /* f32x4[H][W]      history_buffer_specular[...,0] :44 */
+    VRT_BUF_SKY_SCATTERING = 8,   /* f32x3[R][R]      atmos.py:68 */
+    VRT_BUF_SKY_TRANSMITTANCE = 9,/* f32x3[R][R]      atmos.py:69 */
+    VRT_BUF_TRANS_LUT = 10        /* f16x3[256][128]  atmos.py:64 */
+};
+
+/* Renderer.__init__ (pathtracer.py:28). NULL on failure; see vrt_last_error(). */
+vrt_ctx* vrt_create(const vrt_config* cfg);
+void vrt_destroy(vrt_ctx* ctx);
+
+/* Renderer.set_voxel / get_voxel storage (pathtracer.py:1325-1334, voxel_world.py:7-18):
+ * mat int8[128^3], rgb uint8[128^3][3]. */
+int vrt_upload_voxels(vrt_ctx* ctx, const int8_t* mat, const uint8_t* rgb);
+/* MaterialList (materials.py:48-112): 128 rows of 14 f32 in bsdf.py:26-37 field order. */
+int vrt_upload_materials(vrt_ctx* ctx, const float* table);
+/* Atmos.load_textures (atmos.py:85-87): cloud tile uint8[256][256][3] indexed [x][y]. */
+int vrt_upload_cloud_texture(vrt_ctx* ctx, const uint8_t* rgb);
+int vrt_set_scene(vrt_ctx* ctx, const vrt_scene_params* scene);
+int vrt_set_camera(vrt_ctx* ctx, const vrt_camera* cam);
+/* Renderer.prepare_data (pathtracer.py:314-323): packed voxel grid, occupancy pyramid,
+ * and with use_physical_sky the transmittance LUT + cloud ambient + cleared sky tables. */
+int vrt_prepare(vrt_ctx* ctx);
+/* Renderer.accumulate_clouds / compute_atmosphere (pathtracer.py:325-329) */
+int vrt_sky_accumulate_clouds(vrt_ctx* ctx, int max_samples);
+int vrt_sky_compute_slice(vrt_ctx* ctx, int slice_idx, int max_slices);
+/* Renderer.accumulate (pathtracer.py:1310-1319), n_samples times */
+int vrt_accumulate(vrt_ctx* ctx, int n_samples);
+/* Renderer.reset_framebuffer (pathtracer.py:664-668) / copy_prev_matrices (283-287) */
+int vrt_reset(vrt_ctx* ctx);
+int vrt_end_frame(vrt_ctx* ctx);
+/* color_buffer after accumulate() = the HDR frame: f32[H][W][3].  Rows outside
+ * [row_begin,row_end) are zero. */
+int vrt_fetch_hdr(vrt_ctx* ctx, float* out);
+/* same, this context's rows only, copied device-to-device into caller-owned device memory
+ * (f32[row_end-row_begin][W][3]); the call returns after the copy completed. */
+int vrt_fetch_hdr_device(vrt_ctx* ctx, void* device_ptr);
+/* Renderer.fetch_image (pathtracer.py:1321-1323, 634-662): LDR rgba f32[H][W][4] */
+int vrt_fetch_ldr(vrt_ctx* ctx, float* out);
+int vrt_fetch_buffer(vrt_ctx* ctx, int which, void* out);
+int vrt_sync(vrt_ctx* ctx);
+int vrt_get_stats(vrt_ctx* ctx, vrt_stats* out);
+int vrt_reset_stats(vrt_ctx* ctx);
+const char* vrt_last_error(void);
+/* Select the kernel variants that count rays / DDA iterations / occupancy queries / hits
+ * (vrt_stats.rays etc.); off by default -- the counters are what the reference's disabled
+ * iteration heat-map (pathtracer.py:419-425) would have shown. */
+int vrt_set_instrumented(vrt_ctx* ctx, int on);
+/* Evaluate one vrt_detmath.h operation on the device (numeric-contract test hook):
+ * op 0 sin 1 cos 2 exp 3 log 4 pow 5 acos 6 atan2 7 min 8 max 9 f16 round trip 10 a/b 11 sqrt
+ * 12 a*b+a (uncontracted) 13 float->int. */
+int vrt_detmath_probe(int device, int op, int n, const float* a, const float* b, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRT_API_H */

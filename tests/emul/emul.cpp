@@ -1,0 +1,246 @@
+// emul.cpp -- TEST TOOLING: a g++ build of the product's per-path device functions
+// (voxel_rt2_amd/csrc/*.h with VRT_DEV = inline), stepped one pixel at a time on the host.
+// It exists so that the CPU test-suite (no GPU in CI) can check the device code's arithmetic
+// against the oracle bit for bit, and so that sanitizers can run over it.  It is NOT a backend:
+// nothing in voxel_rt2_amd/ links or loads it.
+#include <cstring>
+#include <vector>
+#include "../../include/vrt_api.h"
+#include "../../voxel_rt2_amd/csrc/vrt_types.h"
+#include "../../voxel_rt2_amd/csrc/vrt_trace.h"
+#include "../../voxel_rt2_amd/csrc/vrt_bsdf.h"
+#include "../../voxel_rt2_amd/csrc/vrt_sky.h"
+#include "../../voxel_rt2_amd/csrc/vrt_path.h"
+#include "../../voxel_rt2_amd/csrc/vrt_restir.h"
+#include "../../voxel_rt2_amd/csrc/vrt_temporal.h"
+
+using namespace vrt;
+
+struct Emu {
+    vrt_config cfg;
+    vrt_scene_params scene;
+    vrt_camera cam;
+    std::vector<uint32_t> grid;
+    std::vector<unsigned long long> l0, l1, l2;
+    std::vector<float> mats, sky_scat, sky_trans;
+    int buf0, buf1, own0, own1;
+    size_t n;
+    std::vector<f3> color_d, color_s, color_d2, color_s2, gb_pos, hdr;
+    std::vector<uint32_t> gb_normal[2], gb_mat;
+    std::vector<float> gb_depth[2], gb_refl, gb_refl_f;
+    std::vector<f4> hist_d[2], hist_s[2];
+    std::vector<ReservoirRec> res[2];
+    int cur = 0, hist_in = 0;
+    uint32_t frame = 0;
+    mat4 prev_view{}, prev_proj{};
+    TraceStats ts;
+};
+
+static FrameParams frame_params(const Emu* c) {
+    FrameParams fp;
+    memset(&fp, 0, sizeof(fp));
+    memcpy(fp.view.m, c->cam.view, 64); memcpy(fp.proj.m, c->cam.proj, 64);
+    memcpy(fp.view_inv.m, c->cam.view_inv, 64); memcpy(fp.proj_inv.m, c->cam.proj_inv, 64);
+    fp.prev_view = c->prev_view; fp.prev_proj = c->prev_proj;
+    fp.camera_pos = mk3(c->cam.pos[0], c->cam.pos[1], c->cam.pos[2]);
+    const int W = c->cfg.width, H = c->cfg.height;
+    fp.inv_res = mk2((float)(1.0 / (double)W), (float)(1.0 / (double)H));
+    dm_rng rng = dm_rng_init(c->cfg.seed, c->cam.jitter_index, 0u, 3u);
+    float r0 = dm_rng_f32(&rng), r1 = dm_rng_f32(&rng);
+    fp.taa_jitter = mk2((r0 * 2.0f - 1.0f) * fp.inv_res.x, (r1 * 2.0f - 1.0f) * fp.inv_res.y);
+    fp.W = W; fp.H = H; fp.row0 = c->buf0; fp.row1 = c->buf1;
+    fp.camera_is_moving = c->cam.camera_is_moving;
+    fp.render_scale = c->cam.render_scale; fp.max_accum_frames = c->cam.max_accum_frames;
+    fp.light_dir = mk3(c->scene.light_direction[0], c->scene.light_direction[1], c->scene.light_direction[2]);
+    fp.light_color = mk3(c->scene.light_color[0], c->scene.light_color[1], c->scene.light_color[2]);
+    fp.light_cos_max = c->scene.light_cos_theta_max; fp.light_weight = c->scene.light_weight;
+    fp.floor_height = c->scene.floor_height;
+    fp.floor_color = mk3(c->scene.floor_color[0], c->scene.floor_color[1], c->scene.floor_color[2]);
+    fp.floor_material = c->scene.floor_material;
+    fp.background = mk3(c->scene.background_color[0], c->scene.background_color[1], c->scene.background_color[2]);
+    fp.use_sky = c->scene.use_physical_sky;
+    fp.voxel_edges = c->cfg.voxel_edges; fp.exposure = c->cfg.exposure; fp.max_depth = c->cfg.max_depth;
+    fp.seed = c->cfg.seed; fp.frame = c->frame;
+    return fp;
+}
+
+extern "C" {
+
+Emu* emu_create(const vrt_config* cfg) {
+    Emu* c = new Emu();
+    c->cfg = *cfg;
+    c->own0 = 0; c->own1 = cfg->height;
+    if (cfg->row_end > cfg->row_begin) { c->own0 = cfg->row_begin; c->own1 = cfg->row_end; }
+    int halo = cfg->use_restir ? 26 : 2;
+    c->buf0 = c->own0 - halo < 0 ? 0 : c->own0 - halo;
+    c->buf1 = c->own1 + halo > cfg->height ? cfg->height : c->own1 + halo;
+    size_t n = c->n = (size_t)(c->buf1 - c->buf0) * cfg->width;
+    c->grid.assign(128 * 128 * 128, 0); c->l0.assign(32768, 0); c->l1.assign(512, 0); c->l2.assign(8, 0);
+    c->mats.assign(128 * 14, 0.0f);
+    f3 z = mk3(0.0f);
+    c->color_d.assign(n, z); c->color_s.assign(n, z); c->color_d2.assign(n, z); c->color_s2.assign(n, z);
+    c->gb_pos.assign(n, z); c->hdr.assign(n, z); c->gb_mat.assign(n, 0); c->gb_refl.assign(n, 0); c->gb_refl_f.assign(n, 0);
+    for (int s = 0; s < 2; s++) {
+        c->gb_normal[s].assign(n, 0); c->gb_depth[s].assign(n, 0);
+        c->hist_d[s].assign(n, mk4(0, 0, 0, 0)); c->hist_s[s].assign(n, mk4(0, 0, 0, 0));
+        c->res[s].assign(n, ReservoirRec{});
+    }
+    if (cfg->sky_res > 0) {
+        c->sky_scat.assign((size_t)cfg->sky_res * cfg->sky_res * 3, 0.0f);
+        c->sky_trans.assign((size_t)cfg->sky_res * cfg->sky_res * 3, 0.0f);
+    }
+    stats_zero(c->ts);
+    return c;
+}
+void emu_destroy(Emu* c) { delete c; }
+int emu_upload_voxels(Emu* c, const int8_t* mat, const uint8_t* rgb) {
+    const int n = 128 * 128 * 128;
+    for (int i = 0; i < n; i++) {  // k_pack_grid
+        int m = mat[i];
+        uint32_t a = (m < 0) ? 0u : (uint32_t)m;
+        c->grid[i] = (uint32_t)rgb[3 * i] | ((uint32_t)rgb[3 * i + 1] << 8) | ((uint32_t)rgb[3 * i + 2] << 16) | (a << 24);
+    }
+    for (int b = 0; b < 32768; b++) {  // k_build_l0
+        int bx = b & 31, by = (b >> 5) & 31, bz = b >> 10;
+        unsigned long long w = 0;
+        for (int z = 0; z < 4; z++) for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++)
+            if (mat[((bx * 4 + x) * 128 + (by * 4 + y)) * 128 + (bz * 4 + z)] > 0) w |= 1ULL << (z * 16 + y * 4 + x);
+        c->l0[b] = w;
+    }
+    auto coarse = [](const std::vector<unsigned long long>& fine, std::vector<unsigned long long>& out, int nc) {
+        int nf = nc * 4;
+        for (int b = 0; b < nc * nc * nc; b++) {
+            int bx = b % nc, by = (b / nc) % nc, bz = b / (nc * nc);
+            unsigned long long w = 0;
+            for (int z = 0; z < 4; z++) for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++)
+                if (fine[((bz * 4 + z) * nf + (by * 4 + y)) * nf + (bx * 4 + x)] != 0) w |= 1ULL << (z * 16 + y * 4 + x);
+            out[b] = w;
+        }
+    };
+    coarse(c->l0, c->l1, 8);
+    coarse(c->l1, c->l2, 2);
+    return 0;
+}
+int emu_upload_materials(Emu* c, const float* t) { memcpy(c->mats.data(), t, 128 * 14 * 4); return 0; }
+int emu_upload_cloud_texture(Emu*, const uint8_t*) { return 0; }
+int emu_set_scene(Emu* c, const vrt_scene_params* s) { c->scene = *s; return 0; }
+int emu_set_camera(Emu* c, const vrt_camera* cam) { c->cam = *cam; return 0; }
+int emu_prepare(Emu*) { return 0; }
+int emu_upload_sky(Emu* c, const float* scat, const float* trans) {
+    memcpy(c->sky_scat.data(), scat, c->sky_scat.size() * 4);
+    memcpy(c->sky_trans.data(), trans, c->sky_trans.size() * 4);
+    return 0;
+}
+
+}  // extern "C"
+
+template <bool RESTIR>
+static void render_all(Emu* c, const FrameParams& fp, const SceneData& sc, const PixelBuffers& out) {
+    GlobalPyramid P;
+    P.p = sc.pyr;
+    for (int v = fp.row0; v < fp.row1; v++)
+        for (int u = 0; u < fp.W; u++) {
+            if (outside_render_area(fp, (float)u, (float)v)) continue;
+            Path<RESTIR> p;
+            path_begin(fp, p, u, v);
+            int idx = (v - fp.row0) * fp.W + u;
+            while (!path_segment<RESTIR>(fp, sc, P, out, idx, p, c->ts)) {}
+            path_finish<RESTIR>(fp, sc, out, idx, p, c->ts);
+        }
+}
+
+extern "C" {
+
+int emu_accumulate(Emu* c, int n_samples) {
+    for (int s = 0; s < n_samples; s++) {
+        FrameParams fp = frame_params(c);
+        SceneData sc;
+        sc.pyr.l0 = c->l0.data(); sc.pyr.l1 = c->l1.data(); sc.pyr.l2 = c->l2.data();
+        sc.grid = c->grid.data(); sc.mats = c->mats.data();
+        sc.sky.scattering = c->sky_scat.data(); sc.sky.transmittance = c->sky_trans.data();
+        sc.sky.res = c->cfg.sky_res; sc.sky.fres = c->cfg.sky_res > 0 ? (float)(1.0 / (double)c->cfg.sky_res) : 0.0f;
+        sc.counters = nullptr;
+        PixelBuffers out;
+        out.color_d = c->color_d.data(); out.color_s = c->color_s.data();
+        out.gb_normal = c->gb_normal[c->cur].data(); out.gb_depth = c->gb_depth[c->cur].data();
+        out.gb_refl_depth = c->gb_refl.data(); out.gb_position = c->gb_pos.data(); out.gb_mat = c->gb_mat.data();
+        out.reservoir = c->res[0].data();
+        const f3* cd = c->color_d.data();
+        const f3* cs = c->color_s.data();
+        if (c->cfg.use_restir) {
+            render_all<true>(c, fp, sc, out);
+            GrisBuffers gb;
+            gb.color_d_in = c->color_d.data(); gb.color_s_in = c->color_s.data();
+            gb.color_d_out = c->color_d2.data(); gb.color_s_out = c->color_s2.data();
+            gb.gb_normal = out.gb_normal; gb.gb_depth = out.gb_depth; gb.gb_mat = out.gb_mat;
+            gb.res_in = c->res[0].data(); gb.res_out = c->res[1].data();
+            GlobalPyramid P;
+            P.p = sc.pyr;
+            int g0 = c->own0 - 2 < c->buf0 ? c->buf0 : c->own0 - 2, g1 = c->own1 + 2 > c->buf1 ? c->buf1 : c->own1 + 2;
+            for (int v = g0; v < g1; v++)
+                for (int u = 0; u < fp.W; u++) gris_pixel(fp, sc, P, gb, u, v, 0, 24.0f, 32, 1, c->ts);
+            cd = c->color_d2.data();
+            cs = c->color_s2.data();
+        } else {
+            render_all<false>(c, fp, sc, out);
+        }
+        TemporalBuffers tb;
+        tb.color_d = cd; tb.color_s = cs;
+        tb.gb_normal = out.gb_normal; tb.gb_depth = out.gb_depth; tb.gb_mat = out.gb_mat;
+        tb.gb_refl_raw = c->gb_refl.data(); tb.gb_refl_filtered = c->gb_refl_f.data();
+        tb.hist_d_in = c->hist_d[c->hist_in].data(); tb.hist_d_out = c->hist_d[c->hist_in ^ 1].data();
+        tb.hist_s_in = c->hist_s[c->hist_in].data(); tb.hist_s_out = c->hist_s[c->hist_in ^ 1].data();
+        tb.prev_normal = c->gb_normal[c->cur ^ 1].data(); tb.prev_depth = c->gb_depth[c->cur ^ 1].data();
+        tb.hdr = c->hdr.data();
+        for (int v = c->own0; v < c->own1; v++)
+            for (int u = 0; u < fp.W; u++) temporal_pixel(fp, tb, u, v);
+        c->hist_in ^= 1;
+        c->cur ^= 1;
+        c->frame += 1;
+    }
+    return 0;
+}
+int emu_reset(Emu* c) {
+    for (int s = 0; s < 2; s++) {
+        std::fill(c->hist_d[s].begin(), c->hist_d[s].end(), mk4(0, 0, 0, 0));
+        std::fill(c->hist_s[s].begin(), c->hist_s[s].end(), mk4(0, 0, 0, 0));
+    }
+    return 0;
+}
+int emu_end_frame(Emu* c) { memcpy(c->prev_view.m, c->cam.view, 64); memcpy(c->prev_proj.m, c->cam.proj, 64); return 0; }
+static void fetch_rows(Emu* c, const void* buf, size_t elem, void* out) {
+    size_t W = c->cfg.width;
+    memset(out, 0, (size_t)c->cfg.height * W * elem);
+    memcpy((char*)out + (size_t)c->own0 * W * elem, (const char*)buf + (size_t)(c->own0 - c->buf0) * W * elem,
+           (size_t)(c->own1 - c->own0) * W * elem);
+}
+int emu_fetch_hdr(Emu* c, float* out) { fetch_rows(c, c->hdr.data(), 12, out); return 0; }
+int emu_fetch_ldr(Emu* c, float* out) {
+    FrameParams fp = frame_params(c);
+    std::vector<f4> ldr(c->n);
+    for (int v = c->own0; v < c->own1; v++)
+        for (int u = 0; u < fp.W; u++) ldr[(v - fp.row0) * fp.W + u] = tonemap_pixel(fp, c->hdr.data(), u, v);
+    fetch_rows(c, ldr.data(), 16, out);
+    return 0;
+}
+int emu_fetch_buffer(Emu* c, int which, void* out) {
+    int last = c->cur ^ 1;
+    switch (which) {
+        case VRT_BUF_GBUF_DEPTH: fetch_rows(c, c->gb_depth[last].data(), 4, out); return 0;
+        case VRT_BUF_GBUF_NORMAL: fetch_rows(c, c->gb_normal[last].data(), 4, out); return 0;
+        case VRT_BUF_GBUF_POSITION: fetch_rows(c, c->gb_pos.data(), 12, out); return 0;
+        case VRT_BUF_GBUF_MAT: fetch_rows(c, c->gb_mat.data(), 4, out); return 0;
+        case VRT_BUF_GBUF_REFL_DEPTH: fetch_rows(c, c->gb_refl_f.data(), 4, out); return 0;
+        case VRT_BUF_HISTORY_DIFFUSE: fetch_rows(c, c->hist_d[c->hist_in].data(), 16, out); return 0;
+        case VRT_BUF_HISTORY_SPECULAR: fetch_rows(c, c->hist_s[c->hist_in].data(), 16, out); return 0;
+    }
+    return -1;
+}
+int emu_get_stats(Emu* c, vrt_stats* s) {
+    memset(s, 0, sizeof(*s));
+    s->path_samples = (uint64_t)c->frame * c->cfg.width * (c->own1 - c->own0);
+    s->rays = c->ts.rays; s->dda_iters = c->ts.iters; s->occupancy_queries = c->ts.queries;
+    s->closest_hits = c->ts.closest_hits; s->sky_lookups = c->ts.sky_lookups;
+    return 0;
+}
+}

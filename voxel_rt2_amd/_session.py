@@ -1,0 +1,141 @@
+"""Thin ctypes session over a library exporting the include/vrt_api.h entry points.
+
+In the product the only caller is renderer.Renderer, which passes libvrt_hip.so (loaded by
+_lib.py, which raises if the HIP library is missing -- there is no CPU fallback).  The parity
+tests reuse this class for the test oracle, whose C entry points have the same shapes.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _abi
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class NativeSession:
+    def __init__(self, lib, prefix, cfg, create_extra=()):
+        self._lib, self._p = lib, prefix
+        _abi.declare(lib, prefix)
+        create = getattr(lib, prefix + "create")
+        create.restype = C.c_void_p
+        self.cfg = cfg
+        self.W, self.H = cfg.width, cfg.height
+        self.rows = (cfg.row_begin, cfg.row_end) if cfg.row_end > cfg.row_begin else (0, cfg.height)
+        self._ctx = create(C.byref(cfg), *create_extra)
+        if not self._ctx:
+            raise NativeError(f"{prefix}create failed: {self._err()}")
+
+    def _err(self):
+        fn = getattr(self._lib, self._p + "last_error", None)
+        if fn is None:
+            return "(no message)"
+        msg = fn()
+        return msg.decode() if msg else "(no message)"
+
+    def _call(self, name, *args):
+        if not self._ctx:
+            raise NativeError("session is closed")
+        rc = getattr(self._lib, self._p + name)(C.c_void_p(self._ctx), *args)
+        if rc != 0:
+            raise NativeError(f"{self._p}{name} failed ({rc}): {self._err()}")
+
+    def close(self):
+        if self._ctx:
+            getattr(self._lib, self._p + "destroy")(C.c_void_p(self._ctx))
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- uploads ---------------------------------------------------------------------------
+    def upload_voxels(self, mat, rgb):
+        mat = np.ascontiguousarray(mat, dtype=np.int8)
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        if mat.shape != (128, 128, 128) or rgb.shape != (128, 128, 128, 3):
+            raise ValueError("voxel arrays must be int8[128,128,128] and uint8[128,128,128,3]")
+        self._call("upload_voxels", mat.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p))
+
+    def upload_materials(self, table):
+        table = np.ascontiguousarray(table, dtype=np.float32)
+        if table.shape != (128, 14):
+            raise ValueError("material table must be float32[128,14]")
+        self._call("upload_materials", table.ctypes.data_as(C.c_void_p))
+
+    def upload_cloud_texture(self, tex):
+        tex = np.ascontiguousarray(tex, dtype=np.uint8)
+        if tex.shape != (256, 256, 3):
+            raise ValueError("cloud texture must be uint8[256,256,3]")
+        self._call("upload_cloud_texture", tex.ctypes.data_as(C.c_void_p))
+
+    def set_scene(self, scene):
+        self._call("set_scene", C.byref(scene))
+
+    def set_camera(self, cam):
+        self._call("set_camera", C.byref(cam))
+
+    # -- work ------------------------------------------------------------------------------
+    def prepare(self):
+        self._call("prepare")
+
+    def sky_accumulate_clouds(self, max_samples):
+        self._call("sky_accumulate_clouds", int(max_samples))
+
+    def sky_compute_slice(self, slice_idx, max_slices):
+        self._call("sky_compute_slice", int(slice_idx), int(max_slices))
+
+    def accumulate(self, n=1):
+        self._call("accumulate", int(n))
+
+    def reset(self):
+        self._call("reset")
+
+    def end_frame(self):
+        self._call("end_frame")
+
+    def sync(self):
+        if getattr(self._lib, self._p + "sync", None) is not None:
+            self._call("sync")
+
+    # -- results ---------------------------------------------------------------------------
+    def fetch_hdr(self):
+        out = np.empty((self.H, self.W, 3), dtype=np.float32)
+        self._call("fetch_hdr", out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def fetch_hdr_device(self, device_ptr):
+        self._call("fetch_hdr_device", C.c_void_p(int(device_ptr)))
+
+    def fetch_ldr(self):
+        out = np.empty((self.H, self.W, 4), dtype=np.float32)
+        self._call("fetch_ldr", out.ctypes.data_as(C.c_void_p))
+        return out
+
+    _BUF = {
+        _abi.BUF_GBUF_DEPTH: (np.float32, 1), _abi.BUF_GBUF_NORMAL: (np.uint16, 2), _abi.BUF_GBUF_POSITION: (np.float32, 3),
+        _abi.BUF_GBUF_MAT: (np.uint32, 1), _abi.BUF_GBUF_REFL_DEPTH: (np.float32, 1),
+        _abi.BUF_HISTORY_DIFFUSE: (np.float32, 4), _abi.BUF_HISTORY_SPECULAR: (np.float32, 4),
+    }
+
+    def fetch_buffer(self, which):
+        if which in self._BUF:
+            dt, k = self._BUF[which]
+            out = np.empty((self.H, self.W, k), dtype=dt)
+        elif which in (_abi.BUF_SKY_SCATTERING, _abi.BUF_SKY_TRANSMITTANCE):
+            r = self.cfg.sky_res
+            out = np.empty((r, r, 3), dtype=np.float32)
+        elif which == _abi.BUF_TRANS_LUT:
+            out = np.empty((256, 128, 3), dtype=np.uint16)
+        else:
+            raise ValueError(f"unknown buffer id {which}")
+        self._call("fetch_buffer", int(which), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def stats(self):
+        s = _abi.VrtStats()
+        self._call("get_stats", C.byref(s))
+        return s.as_dict()

@@ -1,0 +1,64 @@
+"""Build libvrt_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m voxel_rt2_amd.build [--force]
+
+Flags that matter for the numeric contract (include/vrt_detmath.h): -ffp-contract=off so no
+a*b+c is fused behind our back, no fast-math, correctly rounded f32 divide / sqrt (hipcc default,
+stated explicitly), denormals kept.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libvrt_hip.so")
+SOURCES = ["vrt_kernels.hip", "vrt_sky_kernels.hip", "vrt_api.hip"]
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-fno-gpu-flush-denormals-to-zero",
+    "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result",
+]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libvrt_hip.so cannot be built (there is no CPU fallback)")
+
+
+def _deps():
+    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    d += [os.path.join(inc, f) for f in os.listdir(inc)]
+    d.append(os.path.abspath(__file__))
+    return d
+
+
+def is_stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(p) > t for p in _deps())
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    if not force and not is_stale():
+        return OUT
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building libvrt_hip.so")
+    if verbose and r.stderr:
+        sys.stderr.write(r.stderr)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

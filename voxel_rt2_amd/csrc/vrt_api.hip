@@ -1,0 +1,531 @@
+// vrt_api.hip -- the C ABI of include/vrt_api.h: context, device memory, launch sequencing.
+//
+// Replaces the host side of the reference's Renderer (renderer/pathtracer.py:28-136 field
+// allocation, 139-150 / 246-287 setters, 314-329 prepare + sky steps, 664-668 reset, 1310-1323
+// accumulate / fetch_image).  One context = one HIP device, one stream; all per-pixel buffers
+// cover the context's rows plus a halo (row-tile sharding across GPUs renders the halo rows
+// redundantly instead of exchanging them: per-pixel random streams make them bit-identical).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/vrt_api.h"
+#include "vrt_kernels.h"
+
+using namespace vrt;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(VRT_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+
+struct EventPair { hipEvent_t a, b; int kind; };  // kind 0 render, 1 temporal, 2 gris
+
+struct vrt_ctx {
+    vrt_config cfg;
+    vrt_scene_params scene;
+    vrt_camera cam;
+    bool have_scene = false, have_cam = false, prepared = false, have_prev = false;
+    bool instrumented = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cu = 0, render_blocks = 0;
+    // rows
+    int own0 = 0, own1 = 0;   // rows this context produces
+    int buf0 = 0, buf1 = 0;   // rows held in the buffers (own + halo)
+    int halo = 2;
+    size_t npix = 0;          // (buf1 - buf0) * W
+    // scene data
+    int8_t* d_mat = nullptr; uint8_t* d_rgb = nullptr; uint32_t* d_grid = nullptr;
+    unsigned long long *d_l0 = nullptr, *d_l1 = nullptr, *d_l2 = nullptr;
+    float* d_mats = nullptr;
+    Counters* d_counters = nullptr;
+    unsigned* d_work = nullptr;
+    // sky
+    float *d_sky_scat = nullptr, *d_sky_trans = nullptr, *d_cloud_ambient = nullptr;
+    uint16_t* d_trans_lut = nullptr;
+    uint8_t* d_cloud_tex = nullptr;
+    uint32_t cloud_pass = 0;
+    // per-pixel
+    f3 *d_color_d = nullptr, *d_color_s = nullptr, *d_color_d2 = nullptr, *d_color_s2 = nullptr, *d_gb_pos = nullptr, *d_hdr = nullptr;
+    uint32_t* d_gb_normal[2] = {nullptr, nullptr};
+    float* d_gb_depth[2] = {nullptr, nullptr};
+    uint32_t* d_gb_mat = nullptr;
+    float *d_gb_refl = nullptr, *d_gb_refl_f = nullptr;
+    f4 *d_hist_d[2] = {nullptr, nullptr}, *d_hist_s[2] = {nullptr, nullptr};
+    f4* d_ldr = nullptr;
+    ReservoirRec* d_res[2] = {nullptr, nullptr};
+    int cur = 0;      // g-buffer ping-pong: render writes [cur], temporal reads [cur ^ 1] as "prev"
+    int hist_in = 0;  // history ping-pong
+    mat4 prev_view{}, prev_proj{};
+    uint32_t frame = 0;
+    // stats
+    std::vector<EventPair> pending;
+    vrt_stats stats{};
+};
+
+template <class T>
+static hipError_t dalloc(T** p, size_t n) {
+    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(T));
+    return e;
+}
+
+static void resolve_events(vrt_ctx* c) {
+    for (auto& ev : c->pending) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+            if (ev.kind == 0) { c->stats.render_ms += ms; c->stats.render_launches++; }
+            else if (ev.kind == 1) { c->stats.temporal_ms += ms; c->stats.temporal_launches++; }
+            else { c->stats.gris_ms += ms; c->stats.gris_launches++; }
+        }
+        hipEventDestroy(ev.a);
+        hipEventDestroy(ev.b);
+    }
+    c->pending.clear();
+}
+
+static FrameParams make_frame_params(const vrt_ctx* c) {
+    FrameParams fp;
+    memset(&fp, 0, sizeof(fp));
+    memcpy(fp.view.m, c->cam.view, 64);
+    memcpy(fp.proj.m, c->cam.proj, 64);
+    memcpy(fp.view_inv.m, c->cam.view_inv, 64);
+    memcpy(fp.proj_inv.m, c->cam.proj_inv, 64);
+    fp.prev_view = c->prev_view;
+    fp.prev_proj = c->prev_proj;
+    fp.camera_pos = mk3(c->cam.pos[0], c->cam.pos[1], c->cam.pos[2]);
+    const int W = c->cfg.width, H = c->cfg.height;
+    fp.inv_res = mk2((float)(1.0 / (double)W), (float)(1.0 / (double)H));
+    // TAA jitter: two draws of random stream 3 per set_proj_mat call (pathtracer.py:264-265)
+    dm_rng rng = dm_rng_init(c->cfg.seed, c->cam.jitter_index, 0u, 3u);
+    float r0 = dm_rng_f32(&rng), r1 = dm_rng_f32(&rng);
+    fp.taa_jitter = mk2((r0 * 2.0f - 1.0f) * fp.inv_res.x, (r1 * 2.0f - 1.0f) * fp.inv_res.y);
+    fp.W = W; fp.H = H;
+    fp.row0 = c->buf0; fp.row1 = c->buf1;
+    fp.camera_is_moving = c->cam.camera_is_moving;
+    fp.render_scale = c->cam.render_scale;
+    fp.max_accum_frames = c->cam.max_accum_frames;
+    fp.light_dir = mk3(c->scene.light_direction[0], c->scene.light_direction[1], c->scene.light_direction[2]);
+    fp.light_color = mk3(c->scene.light_color[0], c->scene.light_color[1], c->scene.light_color[2]);
+    fp.light_cos_max = c->scene.light_cos_theta_max;
+    fp.light_weight = c->scene.light_weight;
+    fp.floor_height = c->scene.floor_height;
+    fp.floor_color = mk3(c->scene.floor_color[0], c->scene.floor_color[1], c->scene.floor_color[2]);
+    fp.floor_material = c->scene.floor_material;
+    fp.background = mk3(c->scene.background_color[0], c->scene.background_color[1], c->scene.background_color[2]);
+    fp.use_sky = c->scene.use_physical_sky;
+    fp.voxel_edges = c->cfg.voxel_edges;
+    fp.exposure = c->cfg.exposure;
+    fp.max_depth = c->cfg.max_depth;
+    fp.seed = c->cfg.seed;
+    fp.frame = c->frame;
+    return fp;
+}
+static SceneData make_scene_data(const vrt_ctx* c) {
+    SceneData sc;
+    sc.pyr.l0 = c->d_l0; sc.pyr.l1 = c->d_l1; sc.pyr.l2 = c->d_l2;
+    sc.grid = c->d_grid;
+    sc.mats = c->d_mats;
+    sc.sky.scattering = c->d_sky_scat;
+    sc.sky.transmittance = c->d_sky_trans;
+    sc.sky.res = c->cfg.sky_res;
+    sc.sky.fres = c->cfg.sky_res > 0 ? (float)(1.0 / (double)c->cfg.sky_res) : 0.0f;
+    sc.counters = c->d_counters;
+    return sc;
+}
+static SkyPrecompute make_sky(const vrt_ctx* c) {
+    SkyPrecompute sp;
+    sp.scattering = c->d_sky_scat; sp.transmittance = c->d_sky_trans; sp.trans_lut = c->d_trans_lut;
+    sp.cloud_tex = c->d_cloud_tex; sp.cloud_ambient = c->d_cloud_ambient;
+    sp.res = c->cfg.sky_res;
+    sp.fres = (float)(1.0 / (double)c->cfg.sky_res);
+    sp.use_clouds = c->scene.use_clouds;
+    sp.seed = c->cfg.seed;
+    return sp;
+}
+static void sun_of(const vrt_ctx* c, f3& dir, f3& col, float& cosm) {
+    dir = mk3(c->scene.light_direction[0], c->scene.light_direction[1], c->scene.light_direction[2]);
+    col = mk3(c->scene.light_color[0], c->scene.light_color[1], c->scene.light_color[2]) * c->scene.light_weight;
+    cosm = c->scene.light_cos_theta_max;
+}
+
+extern "C" {
+
+const char* vrt_last_error(void) { return g_err.c_str(); }
+
+vrt_ctx* vrt_create(const vrt_config* cfg) {
+    if (!cfg) { fail(VRT_E_INVALID, "null config"); return nullptr; }
+    if (cfg->grid_res != 128) { fail(VRT_E_INVALID, "grid_res must be 128 (pathtracer.py:83)"); return nullptr; }
+    if (cfg->width <= 0 || cfg->height <= 0 || cfg->width > 16384 || cfg->height > 16384) { fail(VRT_E_INVALID, "bad image size"); return nullptr; }
+    if (cfg->max_depth < 1 || cfg->max_depth > 64) { fail(VRT_E_INVALID, "max_depth must be in 1..64"); return nullptr; }
+    if (cfg->sky_res < 0 || cfg->sky_res > 8192 || (cfg->sky_res > 0 && cfg->sky_res < 32)) { fail(VRT_E_INVALID, "sky_res must be 0 or 32..8192"); return nullptr; }
+    if (cfg->dx != 1.0f / 64.0f) { fail(VRT_E_INVALID, "dx must be 1/64 (scene.py:11)"); return nullptr; }
+    int own0 = 0, own1 = cfg->height;
+    if (cfg->row_end > cfg->row_begin) {
+        if (cfg->row_begin < 0 || cfg->row_end > cfg->height) { fail(VRT_E_INVALID, "row range outside the image"); return nullptr; }
+        own0 = cfg->row_begin; own1 = cfg->row_end;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fail(VRT_E_DEVICE, "no HIP device: libvrt_hip has no CPU path"); return nullptr; }
+    if (cfg->device < 0 || cfg->device >= ndev) { fail(VRT_E_INVALID, "device ordinal out of range"); return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipSetDevice(cfg->device) != hipSuccess || hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) {
+        fail(VRT_E_DEVICE, "cannot select HIP device");
+        return nullptr;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fail(VRT_E_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+        return nullptr;
+    }
+    vrt_ctx* c = new vrt_ctx();
+    c->cfg = *cfg;
+    c->device = cfg->device;
+    c->n_cu = prop.multiProcessorCount;
+    c->own0 = own0; c->own1 = own1;
+    c->halo = cfg->use_restir ? 26 : 2;  // bilinear + prepass taps; + spatial reuse radius 24 (pathtracer.py:1313)
+    c->buf0 = own0 - c->halo < 0 ? 0 : own0 - c->halo;
+    c->buf1 = own1 + c->halo > cfg->height ? cfg->height : own1 + c->halo;
+    c->npix = (size_t)(c->buf1 - c->buf0) * cfg->width;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    const size_t nvox = (size_t)128 * 128 * 128, n = c->npix;
+    ok = ok && dalloc(&c->d_mat, nvox) == hipSuccess && dalloc(&c->d_rgb, nvox * 3) == hipSuccess && dalloc(&c->d_grid, nvox) == hipSuccess;
+    ok = ok && dalloc(&c->d_l0, 32768) == hipSuccess && dalloc(&c->d_l1, 512) == hipSuccess && dalloc(&c->d_l2, 8) == hipSuccess;
+    ok = ok && dalloc(&c->d_mats, 128 * 14) == hipSuccess && dalloc(&c->d_counters, 1) == hipSuccess && dalloc(&c->d_work, 1) == hipSuccess;
+    ok = ok && dalloc(&c->d_color_d, n) == hipSuccess && dalloc(&c->d_color_s, n) == hipSuccess && dalloc(&c->d_gb_pos, n) == hipSuccess;
+    ok = ok && dalloc(&c->d_hdr, n) == hipSuccess && dalloc(&c->d_gb_mat, n) == hipSuccess && dalloc(&c->d_gb_refl, n) == hipSuccess;
+    ok = ok && dalloc(&c->d_gb_refl_f, n) == hipSuccess && dalloc(&c->d_ldr, n) == hipSuccess;
+    for (int s = 0; s < 2 && ok; s++) {
+        ok = ok && dalloc(&c->d_gb_normal[s], n) == hipSuccess && dalloc(&c->d_gb_depth[s], n) == hipSuccess;
+        ok = ok && dalloc(&c->d_hist_d[s], n) == hipSuccess && dalloc(&c->d_hist_s[s], n) == hipSuccess;
+        if (cfg->use_restir) ok = ok && dalloc(&c->d_res[s], n) == hipSuccess;
+    }
+    if (cfg->use_restir) ok = ok && dalloc(&c->d_color_d2, n) == hipSuccess && dalloc(&c->d_color_s2, n) == hipSuccess;
+    if (cfg->sky_res > 0) {
+        size_t ns = (size_t)cfg->sky_res * cfg->sky_res * 3;
+        ok = ok && dalloc(&c->d_sky_scat, ns) == hipSuccess && dalloc(&c->d_sky_trans, ns) == hipSuccess;
+        ok = ok && dalloc(&c->d_trans_lut, 256 * 128 * 3) == hipSuccess && dalloc(&c->d_cloud_tex, 256 * 256 * 3) == hipSuccess;
+        ok = ok && dalloc(&c->d_cloud_ambient, 4) == hipSuccess;
+    }
+    if (!ok) {
+        fail(VRT_E_DEVICE, std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError()));
+        vrt_destroy(c);
+        return nullptr;
+    }
+    // default material table rows (materials.py:50-63) until vrt_upload_materials is called
+    {
+        std::vector<float> t(128 * 14);
+        const float row[14] = {1, 1, 1, 0, 0, 0.04f, 0, 0.9f, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 128; i++) memcpy(&t[14 * i], row, sizeof(row));
+        hipMemcpy(c->d_mats, t.data(), t.size() * 4, hipMemcpyHostToDevice);
+    }
+    memset(&c->scene, 0, sizeof(c->scene));
+    c->scene.floor_color[0] = c->scene.floor_color[1] = c->scene.floor_color[2] = 1.0f;  // pathtracer.py:91-93
+    c->scene.floor_material = 1;
+    c->scene.light_cos_theta_max = 1.0f;
+    return c;
+}
+
+void vrt_destroy(vrt_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    resolve_events(c);
+    void* ptrs[] = {c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_mats, c->d_counters, c->d_work, c->d_sky_scat,
+                    c->d_sky_trans, c->d_cloud_ambient, c->d_trans_lut, c->d_cloud_tex, c->d_color_d, c->d_color_s, c->d_color_d2,
+                    c->d_color_s2, c->d_gb_pos, c->d_hdr, c->d_gb_normal[0], c->d_gb_normal[1], c->d_gb_depth[0], c->d_gb_depth[1],
+                    c->d_gb_mat, c->d_gb_refl, c->d_gb_refl_f, c->d_hist_d[0], c->d_hist_d[1], c->d_hist_s[0], c->d_hist_s[1],
+                    c->d_ldr, c->d_res[0], c->d_res[1]};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int vrt_upload_voxels(vrt_ctx* c, const int8_t* mat, const uint8_t* rgb) {
+    if (!c || !mat || !rgb) return fail(VRT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t nvox = (size_t)128 * 128 * 128;
+    HIP_TRY(hipMemcpyAsync(c->d_mat, mat, nvox, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_rgb, rgb, nvox * 3, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // host buffers are only borrowed for the call
+    c->prepared = false;
+    return VRT_OK;
+}
+int vrt_upload_materials(vrt_ctx* c, const float* table) {
+    if (!c || !table) return fail(VRT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->d_mats, table, 128 * 14 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+int vrt_upload_cloud_texture(vrt_ctx* c, const uint8_t* rgb) {
+    if (!c || !rgb) return fail(VRT_E_INVALID, "null argument");
+    if (c->cfg.sky_res <= 0) return fail(VRT_E_STATE, "context was created without sky tables (sky_res = 0)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->d_cloud_tex, rgb, 256 * 256 * 3, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+int vrt_set_scene(vrt_ctx* c, const vrt_scene_params* s) {
+    if (!c || !s) return fail(VRT_E_INVALID, "null argument");
+    if (s->use_physical_sky && c->cfg.sky_res <= 0) return fail(VRT_E_INVALID, "use_physical_sky needs sky_res > 0 at vrt_create");
+    c->scene = *s;
+    c->have_scene = true;
+    return VRT_OK;
+}
+int vrt_set_camera(vrt_ctx* c, const vrt_camera* cam) {
+    if (!c || !cam) return fail(VRT_E_INVALID, "null argument");
+    if (!(cam->render_scale > 0.0f) || cam->render_scale > 1.0f) return fail(VRT_E_INVALID, "render_scale must be in (0, 1]");
+    if (cam->camera_is_moving && (c->own0 != 0 || c->own1 != c->cfg.height))
+        return fail(VRT_E_INVALID, "row-sharded contexts support the static camera only (history resampling crosses tiles)");
+    c->cam = *cam;
+    c->have_cam = true;
+    return VRT_OK;
+}
+int vrt_set_instrumented(vrt_ctx* c, int on) {
+    if (!c) return fail(VRT_E_INVALID, "null context");
+    c->instrumented = on != 0;
+    c->render_blocks = 0;
+    return VRT_OK;
+}
+
+int vrt_prepare(vrt_ctx* c) {
+    if (!c) return fail(VRT_E_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_prepare(c->stream, c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2));
+    if (c->scene.use_physical_sky == 1) {
+        SkyPrecompute sp = make_sky(c);
+        f3 sd, sc_;
+        float cm;
+        sun_of(c, sd, sc_, cm);
+        size_t ns = (size_t)c->cfg.sky_res * c->cfg.sky_res * 3 * sizeof(float);
+        HIP_TRY(launch_sky_prepare(c->stream, sp, sd, sc_, cm));
+        HIP_TRY(hipMemsetAsync(c->d_sky_scat, 0, ns, c->stream));   // pathtracer.py:322-323
+        HIP_TRY(hipMemsetAsync(c->d_sky_trans, 0, ns, c->stream));
+        c->cloud_pass = 0;
+    }
+    c->prepared = true;
+    return VRT_OK;
+}
+int vrt_sky_accumulate_clouds(vrt_ctx* c, int max_samples) {
+    if (!c || max_samples <= 0) return fail(VRT_E_INVALID, "bad argument");
+    if (!c->prepared || c->scene.use_physical_sky != 1) return fail(VRT_E_STATE, "needs vrt_prepare with use_physical_sky");
+    HIP_TRY(hipSetDevice(c->device));
+    f3 sd, sc_;
+    float cm;
+    sun_of(c, sd, sc_, cm);
+    HIP_TRY(launch_sky_clouds(c->stream, make_sky(c), sd, sc_, cm, max_samples, c->cloud_pass));
+    c->cloud_pass++;
+    return VRT_OK;
+}
+int vrt_sky_compute_slice(vrt_ctx* c, int slice_idx, int max_slices) {
+    if (!c || max_slices <= 0 || slice_idx < 0 || slice_idx >= max_slices) return fail(VRT_E_INVALID, "bad slice");
+    if (!c->prepared || c->scene.use_physical_sky != 1) return fail(VRT_E_STATE, "needs vrt_prepare with use_physical_sky");
+    HIP_TRY(hipSetDevice(c->device));
+    f3 sd, sc_;
+    float cm;
+    sun_of(c, sd, sc_, cm);
+    int w = c->cfg.sky_res / max_slices;  // atmos.py:162
+    HIP_TRY(launch_sky_slice(c->stream, make_sky(c), sd, sc_, cm, w * slice_idx, w * (slice_idx + 1)));
+    return VRT_OK;
+}
+
+static int record(vrt_ctx* c, int kind, hipEvent_t* a, hipEvent_t* b) {
+    HIP_TRY(hipEventCreate(a));
+    HIP_TRY(hipEventCreate(b));
+    c->pending.push_back(EventPair{*a, *b, kind});
+    return VRT_OK;
+}
+
+int vrt_accumulate(vrt_ctx* c, int n_samples) {
+    if (!c || n_samples < 0) return fail(VRT_E_INVALID, "bad argument");
+    if (!c->prepared) return fail(VRT_E_STATE, "vrt_prepare has not run since the last voxel upload");
+    if (!c->have_cam) return fail(VRT_E_STATE, "vrt_set_camera has not been called");
+    HIP_TRY(hipSetDevice(c->device));
+    const bool restir = c->cfg.use_restir != 0, instr = c->instrumented;
+    if (c->render_blocks == 0) {
+        int per_cu = 0;
+        HIP_TRY(query_render_residency(restir, instr, &per_cu));
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 8) per_cu = 8;
+        c->render_blocks = per_cu * c->n_cu;
+    }
+    for (int s = 0; s < n_samples; s++) {
+        if (c->pending.size() > 192) resolve_events(c);
+        FrameParams fp = make_frame_params(c);
+        SceneData sc = make_scene_data(c);
+        PixelBuffers out;
+        out.color_d = c->d_color_d; out.color_s = c->d_color_s;
+        out.gb_normal = c->d_gb_normal[c->cur]; out.gb_depth = c->d_gb_depth[c->cur];
+        out.gb_refl_depth = c->d_gb_refl; out.gb_position = c->d_gb_pos; out.gb_mat = c->d_gb_mat;
+        out.reservoir = c->d_res[0];
+        hipEvent_t a, b;
+        if (record(c, 0, &a, &b) != VRT_OK) return VRT_E_DEVICE;
+        HIP_TRY(hipEventRecord(a, c->stream));
+        HIP_TRY(launch_render(c->stream, restir, instr, c->render_blocks, fp, sc, out, c->d_work));
+        HIP_TRY(hipEventRecord(b, c->stream));
+        const f3* cd = c->d_color_d;
+        const f3* cs = c->d_color_s;
+        if (restir) {
+            GrisBuffers gb;
+            gb.color_d_in = c->d_color_d; gb.color_s_in = c->d_color_s; gb.color_d_out = c->d_color_d2; gb.color_s_out = c->d_color_s2;
+            gb.gb_normal = out.gb_normal; gb.gb_depth = out.gb_depth; gb.gb_mat = out.gb_mat;
+            gb.res_in = c->d_res[0]; gb.res_out = c->d_res[1];
+            int g0 = c->own0 - 2 < c->buf0 ? c->buf0 : c->own0 - 2, g1 = c->own1 + 2 > c->buf1 ? c->buf1 : c->own1 + 2;
+            if (record(c, 2, &a, &b) != VRT_OK) return VRT_E_DEVICE;
+            HIP_TRY(hipEventRecord(a, c->stream));
+            HIP_TRY(launch_gris(c->stream, instr, fp, sc, gb, g0, g1));
+            HIP_TRY(hipEventRecord(b, c->stream));
+            cd = c->d_color_d2;
+            cs = c->d_color_s2;
+        }
+        TemporalBuffers tb;
+        tb.color_d = cd; tb.color_s = cs;
+        tb.gb_normal = out.gb_normal; tb.gb_depth = out.gb_depth; tb.gb_mat = out.gb_mat;
+        tb.gb_refl_raw = c->d_gb_refl; tb.gb_refl_filtered = c->d_gb_refl_f;
+        tb.hist_d_in = c->d_hist_d[c->hist_in]; tb.hist_d_out = c->d_hist_d[c->hist_in ^ 1];
+        tb.hist_s_in = c->d_hist_s[c->hist_in]; tb.hist_s_out = c->d_hist_s[c->hist_in ^ 1];
+        tb.prev_normal = c->d_gb_normal[c->cur ^ 1]; tb.prev_depth = c->d_gb_depth[c->cur ^ 1];
+        tb.hdr = c->d_hdr;
+        if (record(c, 1, &a, &b) != VRT_OK) return VRT_E_DEVICE;
+        HIP_TRY(hipEventRecord(a, c->stream));
+        HIP_TRY(launch_temporal(c->stream, fp, tb, c->own0, c->own1));
+        HIP_TRY(hipEventRecord(b, c->stream));
+        // pathtracer.py:1298-1303 copy loop == pointer swaps
+        c->hist_in ^= 1;
+        c->cur ^= 1;
+        c->frame += 1;
+        c->stats.path_samples += (uint64_t)c->cfg.width * (uint64_t)(c->own1 - c->own0);
+    }
+    return VRT_OK;
+}
+
+int vrt_reset(vrt_ctx* c) {
+    if (!c) return fail(VRT_E_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    for (int s = 0; s < 2; s++) {
+        HIP_TRY(hipMemsetAsync(c->d_hist_d[s], 0, c->npix * sizeof(f4), c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_hist_s[s], 0, c->npix * sizeof(f4), c->stream));
+    }
+    return VRT_OK;
+}
+int vrt_end_frame(vrt_ctx* c) {
+    if (!c) return fail(VRT_E_INVALID, "null context");
+    memcpy(c->prev_view.m, c->cam.view, 64);
+    memcpy(c->prev_proj.m, c->cam.proj, 64);
+    c->have_prev = true;
+    return VRT_OK;
+}
+int vrt_sync(vrt_ctx* c) {
+    if (!c) return fail(VRT_E_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+
+// copy rows [own0, own1) of a per-pixel device buffer into a full-image host array (other rows zero)
+static int fetch_rows(vrt_ctx* c, const void* dbuf, size_t elem, void* out) {
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t W = c->cfg.width;
+    memset(out, 0, (size_t)c->cfg.height * W * elem);
+    const char* src = (const char*)dbuf + (size_t)(c->own0 - c->buf0) * W * elem;
+    char* dst = (char*)out + (size_t)c->own0 * W * elem;
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)(c->own1 - c->own0) * W * elem, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+int vrt_fetch_hdr(vrt_ctx* c, float* out) {
+    if (!c || !out) return fail(VRT_E_INVALID, "null argument");
+    return fetch_rows(c, c->d_hdr, sizeof(f3), out);
+}
+int vrt_fetch_hdr_device(vrt_ctx* c, void* device_ptr) {
+    if (!c || !device_ptr) return fail(VRT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t W = c->cfg.width;
+    const char* src = (const char*)c->d_hdr + (size_t)(c->own0 - c->buf0) * W * sizeof(f3);
+    HIP_TRY(hipMemcpyAsync(device_ptr, src, (size_t)(c->own1 - c->own0) * W * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+int vrt_fetch_ldr(vrt_ctx* c, float* out) {
+    if (!c || !out) return fail(VRT_E_INVALID, "null argument");
+    if (!c->have_cam) return fail(VRT_E_STATE, "vrt_set_camera has not been called");
+    HIP_TRY(hipSetDevice(c->device));
+    FrameParams fp = make_frame_params(c);
+    HIP_TRY(launch_tonemap(c->stream, fp, c->d_hdr, c->d_ldr, c->own0, c->own1));
+    return fetch_rows(c, c->d_ldr, sizeof(f4), out);
+}
+int vrt_fetch_buffer(vrt_ctx* c, int which, void* out) {
+    if (!c || !out) return fail(VRT_E_INVALID, "null argument");
+    const int last = c->cur ^ 1;  // g-buffer written by the most recent accumulate
+    switch (which) {
+        case VRT_BUF_GBUF_DEPTH: return fetch_rows(c, c->d_gb_depth[last], 4, out);
+        case VRT_BUF_GBUF_NORMAL: return fetch_rows(c, c->d_gb_normal[last], 4, out);
+        case VRT_BUF_GBUF_POSITION: return fetch_rows(c, c->d_gb_pos, 12, out);
+        case VRT_BUF_GBUF_MAT: return fetch_rows(c, c->d_gb_mat, 4, out);
+        case VRT_BUF_GBUF_REFL_DEPTH: return fetch_rows(c, c->d_gb_refl_f, 4, out);
+        case VRT_BUF_HISTORY_DIFFUSE: return fetch_rows(c, c->d_hist_d[c->hist_in], 16, out);
+        case VRT_BUF_HISTORY_SPECULAR: return fetch_rows(c, c->d_hist_s[c->hist_in], 16, out);
+        default: break;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    if (which == VRT_BUF_SKY_SCATTERING || which == VRT_BUF_SKY_TRANSMITTANCE) {
+        if (c->cfg.sky_res <= 0) return fail(VRT_E_STATE, "no sky tables");
+        size_t ns = (size_t)c->cfg.sky_res * c->cfg.sky_res * 3 * sizeof(float);
+        HIP_TRY(hipMemcpyAsync(out, which == VRT_BUF_SKY_SCATTERING ? c->d_sky_scat : c->d_sky_trans, ns, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return VRT_OK;
+    }
+    if (which == VRT_BUF_TRANS_LUT) {
+        if (c->cfg.sky_res <= 0) return fail(VRT_E_STATE, "no sky tables");
+        HIP_TRY(hipMemcpyAsync(out, c->d_trans_lut, 256 * 128 * 3 * 2, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return VRT_OK;
+    }
+    return fail(VRT_E_INVALID, "unknown buffer id");
+}
+int vrt_get_stats(vrt_ctx* c, vrt_stats* out) {
+    if (!c || !out) return fail(VRT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    resolve_events(c);
+    Counters h;
+    HIP_TRY(hipMemcpy(&h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    c->stats.rays = h.rays; c->stats.dda_iters = h.iters; c->stats.occupancy_queries = h.queries;
+    c->stats.closest_hits = h.closest_hits; c->stats.sky_lookups = h.sky_lookups;
+    *out = c->stats;
+    return VRT_OK;
+}
+int vrt_reset_stats(vrt_ctx* c) {
+    if (!c) return fail(VRT_E_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    resolve_events(c);
+    HIP_TRY(hipMemset(c->d_counters, 0, sizeof(Counters)));
+    memset(&c->stats, 0, sizeof(c->stats));
+    return VRT_OK;
+}
+// runs op over n floats on the device: checks the numeric contract of vrt_detmath.h on gfx950
+int vrt_detmath_probe(int device, int op, int n, const float* a, const float* b, float* out) {
+    if (n <= 0 || !a || !b || !out) return fail(VRT_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void**)&da, n * 4));
+    HIP_TRY(hipMalloc((void**)&db, n * 4));
+    HIP_TRY(hipMalloc((void**)&dout, n * 4));
+    HIP_TRY(hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(launch_detmath_probe(0, op, n, da, db, dout));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db); hipFree(dout);
+    return VRT_OK;
+}
+
+}  // extern "C"

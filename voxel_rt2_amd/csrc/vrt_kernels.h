@@ -1,0 +1,46 @@
+// vrt_kernels.h -- launcher declarations shared by vrt_kernels.hip, vrt_sky_kernels.hip and vrt_api.hip.
+#ifndef VRT_KERNELS_H
+#define VRT_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include "vrt_types.h"
+#include "vrt_trace.h"
+#include "vrt_bsdf.h"
+#include "vrt_sky.h"
+#include "vrt_path.h"
+#include "vrt_restir.h"
+#include "vrt_temporal.h"
+
+#define VRT_RENDER_THREADS 256
+
+namespace vrt {
+
+hipError_t launch_prepare(hipStream_t st, const int8_t* mat, const uint8_t* rgb, uint32_t* grid, unsigned long long* l0,
+                          unsigned long long* l1, unsigned long long* l2);
+hipError_t query_render_residency(bool restir, bool instr, int* blocks_per_cu);
+hipError_t launch_render(hipStream_t st, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
+                         const PixelBuffers& out, unsigned* work_counter);
+hipError_t launch_gris(hipStream_t st, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1);
+hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1);
+hipError_t launch_tonemap(hipStream_t st, const FrameParams& fp, const f3* hdr, f4* ldr, int r0, int r1);
+hipError_t launch_detmath_probe(hipStream_t st, int op, int n, const float* a, const float* b, float* out);
+
+// sky precompute (vrt_sky_kernels.hip)
+struct SkyPrecompute {
+    float* scattering;        // [res][res][3]
+    float* transmittance;     // [res][res][3]
+    uint16_t* trans_lut;      // [256][128][3] binary16
+    const uint8_t* cloud_tex; // [256][256][3]
+    float* cloud_ambient;     // [3]
+    int res;
+    float fres;
+    int use_clouds;
+    uint32_t seed;
+};
+hipError_t launch_sky_prepare(hipStream_t st, const SkyPrecompute& sp, f3 sun_dir, f3 sun_col, float sun_cos);
+hipError_t launch_sky_clouds(hipStream_t st, const SkyPrecompute& sp, f3 sun_dir, f3 sun_col, float sun_cos, int max_samples,
+                             uint32_t pass);
+hipError_t launch_sky_slice(hipStream_t st, const SkyPrecompute& sp, f3 sun_dir, f3 sun_col, float sun_cos, int u0, int u1);
+
+}  // namespace vrt
+#endif

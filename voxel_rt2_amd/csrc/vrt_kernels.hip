@@ -1,0 +1,266 @@
+// vrt_kernels.hip -- gfx950 kernels of libvrt_hip.so.
+//
+//   k_pack_grid / k_build_l0 / k_build_l1 / k_build_l2   prepare_data: packed voxel texels and
+//                                                         the bit-brick occupancy pyramid
+//   k_render<RESTIR, INSTR>                               persistent wave64 path tracer
+//   k_gris                                                ReSTIR spatial reuse
+//   k_temporal                                            fused temporal accumulation -> HDR
+//   k_tonemap                                             LDR presentation
+//
+// k_render is a persistent-thread kernel: the grid is sized to the device's residency, each wave
+// keeps 64 path records in registers and pulls pixels (8x8 tiles, tile-major order) from a global
+// counter.  Between path segments lanes whose path has ended are compacted out with
+// __ballot/__popcll and refilled, so the wave's lanes are at different bounce depths but all busy.
+// The two coarse brick levels of the pyramid (4 KiB + 64 B) and the material table (7 KiB) are
+// staged in LDS once per workgroup; the fine brick level (256 KiB) and the texel grid (8 MiB) stay
+// in L2 / Infinity Cache.  Every wave reaches the exit: the loop ends when the counter is exhausted
+// and no lane holds a path.
+#include <hip/hip_runtime.h>
+#include "vrt_kernels.h"
+
+namespace vrt {
+
+// ---- prepare_data ----------------------------------------------------------------------------
+// voxel_world.py:69-87: rgba8 texel per voxel; a negative material byte stores 0 (unorm clamp)
+__global__ void k_pack_grid(const int8_t* __restrict__ mat, const uint8_t* __restrict__ rgb, uint32_t* __restrict__ grid, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int m = mat[i];
+    uint32_t a = (m < 0) ? 0u : (uint32_t)m;
+    grid[i] = (uint32_t)rgb[3 * i] | ((uint32_t)rgb[3 * i + 1] << 8) | ((uint32_t)rgb[3 * i + 2] << 16) | (a << 24);
+}
+// raytracer.py:46-53: LOD-0 bit = voxel_material > 0 (signed), gathered into one 4x4x4 brick word per thread
+__global__ void k_build_l0(const int8_t* __restrict__ mat, unsigned long long* __restrict__ l0) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= 32 * 32 * 32) return;
+    int bx = b & 31, by = (b >> 5) & 31, bz = b >> 10;
+    unsigned long long w = 0ULL;
+    for (int z = 0; z < 4; z++)
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++) {
+                int vx = bx * 4 + x, vy = by * 4 + y, vz = bz * 4 + z;
+                if (mat[(vx * VRT_GRID + vy) * VRT_GRID + vz] > 0) w |= 1ULL << (z * 16 + y * 4 + x);
+            }
+    l0[b] = w;
+}
+// raytracer.py:54-70: a coarser cell is occupied if any child is; here one bit per non-zero child word
+__global__ void k_build_coarse(const unsigned long long* __restrict__ fine, unsigned long long* __restrict__ coarse, int n_coarse) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = n_coarse * n_coarse * n_coarse;
+    if (b >= total) return;
+    int n_fine = n_coarse * 4;
+    int bx = b % n_coarse, by = (b / n_coarse) % n_coarse, bz = b / (n_coarse * n_coarse);
+    unsigned long long w = 0ULL;
+    for (int z = 0; z < 4; z++)
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++) {
+                int fx = bx * 4 + x, fy = by * 4 + y, fz = bz * 4 + z;
+                if (fine[(fz * n_fine + fy) * n_fine + fx] != 0ULL) w |= 1ULL << (z * 16 + y * 4 + x);
+            }
+    coarse[b] = w;
+}
+
+// ---- render ----------------------------------------------------------------------------------
+struct LdsPyramid {  // coarse levels in LDS, fine level through L2
+    const unsigned long long* l0;
+    const unsigned long long* l1;
+    const unsigned long long* l2;
+    __device__ __forceinline__ unsigned long long load_l0(int i) const { return l0[i]; }
+    __device__ __forceinline__ unsigned long long load_l1(int i) const { return l1[i]; }
+    __device__ __forceinline__ unsigned long long load_l2(int i) const { return l2[i]; }
+};
+
+__device__ __forceinline__ void flush_stats(const TraceStats& ts, Counters* c) {
+    // wave-level sum, one atomic per counter per wave
+    unsigned v[5] = {ts.rays, ts.iters, ts.queries, ts.closest_hits, ts.sky_lookups};
+    unsigned long long* dst[5] = {&c->rays, &c->iters, &c->queries, &c->closest_hits, &c->sky_lookups};
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        unsigned long long s = v[k];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(dst[k], s);
+    }
+}
+
+template <bool RESTIR, bool INSTR>
+__global__ __launch_bounds__(VRT_RENDER_THREADS) void k_render(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter) {
+    __shared__ unsigned long long s_l1[512];
+    __shared__ unsigned long long s_l2[8];
+    __shared__ float s_mats[128 * 14];
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
+    if (threadIdx.x < 8) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
+    for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
+    __syncthreads();
+    LdsPyramid P;
+    P.l0 = sc.pyr.l0; P.l1 = s_l1; P.l2 = s_l2;
+    SceneData scl = sc;
+    scl.mats = s_mats;
+
+    const int lane = threadIdx.x & 63;
+    const int tiles_x = (fp.W + 7) >> 3;
+    const int tiles_y = (fp.row1 - fp.row0 + 7) >> 3;
+    const unsigned total = (unsigned)(tiles_x * tiles_y) * 64u;
+
+    Path<RESTIR> p;
+    p.depth = -1;
+    int local_idx = 0;
+    TraceStats ts;
+    stats_zero(ts);
+    bool exhausted = false;  // wave-uniform
+
+    for (;;) {
+        const bool need = p.depth < 0;
+        const unsigned long long mask = __ballot(need);
+        if (mask != 0ULL && !exhausted) {
+            const unsigned n = (unsigned)__popcll(mask);
+            unsigned base = 0u;
+            if (lane == (int)__ffsll((long long)mask) - 1) base = atomicAdd(work_counter, n);
+            base = (unsigned)__shfl((int)base, (int)__ffsll((long long)mask) - 1, 64);
+            if (base + n >= total) exhausted = true;
+            const unsigned my = base + (unsigned)__popcll(mask & ((1ULL << lane) - 1ULL));
+            if (need && my < total) {
+                const unsigned tile = my >> 6, in = my & 63u;
+                const int u = (int)(tile % (unsigned)tiles_x) * 8 + (int)(in & 7u);
+                const int v = fp.row0 + (int)(tile / (unsigned)tiles_x) * 8 + (int)(in >> 3);
+                if (u < fp.W && v < fp.row1 && !outside_render_area(fp, (float)u, (float)v)) {
+                    path_begin(fp, p, u, v);
+                    local_idx = (v - fp.row0) * fp.W + u;
+                }
+            }
+        }
+        if (__ballot(p.depth >= 0) == 0ULL) {
+            if (exhausted) break;
+            continue;
+        }
+        if (p.depth >= 0) {
+            const bool done = path_segment<RESTIR>(fp, scl, P, out, local_idx, p, ts);
+            if (done) {
+                path_finish<RESTIR>(fp, scl, out, local_idx, p, ts);
+                p.depth = -1;
+            }
+        }
+    }
+    if (INSTR) flush_stats(ts, sc.counters);
+}
+
+// ---- spatial reuse ---------------------------------------------------------------------------
+template <bool INSTR>
+__global__ __launch_bounds__(256) void k_gris(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r1) {
+    __shared__ unsigned long long s_l1[512];
+    __shared__ unsigned long long s_l2[8];
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
+    if (threadIdx.x < 8) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
+    __syncthreads();
+    LdsPyramid P;
+    P.l0 = sc.pyr.l0; P.l1 = s_l1; P.l2 = s_l2;
+    // 16x16 pixel tile per workgroup = four 8x8 wave tiles
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int u = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int v = r0 + blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    TraceStats ts;
+    stats_zero(ts);
+    if (u < fp.W && v < r1) gris_pixel(fp, sc, P, gb, u, v, 0, 24.0f, 32, 1, ts);
+    if (INSTR) flush_stats(ts, sc.counters);
+}
+
+// ---- temporal accumulation + presentation ------------------------------------------------------
+__global__ __launch_bounds__(256) void k_temporal(FrameParams fp, TemporalBuffers tb, int r0, int r1) {
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int v = r0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u < fp.W && v < r1) temporal_pixel(fp, tb, u, v);
+}
+__global__ __launch_bounds__(256) void k_tonemap(FrameParams fp, const f3* hdr, f4* ldr, int r0, int r1) {
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int v = r0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u < fp.W && v < r1) ldr[(v - fp.row0) * fp.W + u] = tonemap_pixel(fp, hdr, u, v);
+}
+__global__ void k_detmath_probe(int op, int n, const float* a, const float* b, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = 0.0f;
+    switch (op) {
+        case 0: r = dm_sin(a[i]); break;
+        case 1: r = dm_cos(a[i]); break;
+        case 2: r = dm_exp(a[i]); break;
+        case 3: r = dm_log(a[i]); break;
+        case 4: r = dm_pow(a[i], b[i]); break;
+        case 5: r = dm_acos(a[i]); break;
+        case 6: r = dm_atan2(a[i], b[i]); break;
+        case 7: r = dm_min(a[i], b[i]); break;
+        case 8: r = dm_max(a[i], b[i]); break;
+        case 9: r = dm_round_f16(a[i]); break;
+        case 10: r = a[i] / b[i]; break;
+        case 11: r = dm_sqrt(a[i]); break;
+        case 12: r = a[i] * b[i] + a[i]; break;  // must NOT contract
+        case 13: r = (float)dm_f2i(a[i]); break;
+    }
+    out[i] = r;
+}
+
+// ---- host-side launchers -----------------------------------------------------------------------
+#define VRT_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t launch_prepare(hipStream_t st, const int8_t* mat, const uint8_t* rgb, uint32_t* grid, unsigned long long* l0,
+                          unsigned long long* l1, unsigned long long* l2) {
+    const int n = VRT_GRID * VRT_GRID * VRT_GRID;
+    hipLaunchKernelGGL(k_pack_grid, dim3((n + 255) / 256), dim3(256), 0, st, mat, rgb, grid, n);
+    VRT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_build_l0, dim3(32 * 32 * 32 / 256), dim3(256), 0, st, mat, l0);
+    VRT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_build_coarse, dim3(2), dim3(256), 0, st, (const unsigned long long*)l0, l1, 8);
+    VRT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_build_coarse, dim3(1), dim3(64), 0, st, (const unsigned long long*)l1, l2, 2);
+    VRT_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+template <bool RESTIR, bool INSTR>
+static hipError_t render_blocks_per_cu(int* out) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, k_render<RESTIR, INSTR>, VRT_RENDER_THREADS, 0);
+}
+hipError_t query_render_residency(bool restir, bool instr, int* blocks_per_cu) {
+    if (restir) return instr ? render_blocks_per_cu<true, true>(blocks_per_cu) : render_blocks_per_cu<true, false>(blocks_per_cu);
+    return instr ? render_blocks_per_cu<false, true>(blocks_per_cu) : render_blocks_per_cu<false, false>(blocks_per_cu);
+}
+
+hipError_t launch_render(hipStream_t st, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
+                         const PixelBuffers& out, unsigned* work_counter) {
+    hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(unsigned), st);
+    if (e != hipSuccess) return e;
+    dim3 g(n_blocks), b(VRT_RENDER_THREADS);
+    if (restir) {
+        if (instr) hipLaunchKernelGGL((k_render<true, true>), g, b, 0, st, fp, sc, out, work_counter);
+        else hipLaunchKernelGGL((k_render<true, false>), g, b, 0, st, fp, sc, out, work_counter);
+    } else {
+        if (instr) hipLaunchKernelGGL((k_render<false, true>), g, b, 0, st, fp, sc, out, work_counter);
+        else hipLaunchKernelGGL((k_render<false, false>), g, b, 0, st, fp, sc, out, work_counter);
+    }
+    VRT_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_gris(hipStream_t st, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1) {
+    dim3 g((fp.W + 15) / 16, (r1 - r0 + 15) / 16), b(256);
+    if (instr) hipLaunchKernelGGL((k_gris<true>), g, b, 0, st, fp, sc, gb, r0, r1);
+    else hipLaunchKernelGGL((k_gris<false>), g, b, 0, st, fp, sc, gb, r0, r1);
+    VRT_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1) {
+    dim3 g((fp.W + 63) / 64, (r1 - r0 + 3) / 4), b(256);
+    hipLaunchKernelGGL(k_temporal, g, b, 0, st, fp, tb, r0, r1);
+    VRT_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_tonemap(hipStream_t st, const FrameParams& fp, const f3* hdr, f4* ldr, int r0, int r1) {
+    dim3 g((fp.W + 63) / 64, (r1 - r0 + 3) / 4), b(256);
+    hipLaunchKernelGGL(k_tonemap, g, b, 0, st, fp, hdr, ldr, r0, r1);
+    VRT_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_detmath_probe(hipStream_t st, int op, int n, const float* a, const float* b, float* out) {
+    hipLaunchKernelGGL(k_detmath_probe, dim3((n + 255) / 256), dim3(256), 0, st, op, n, a, b, out);
+    VRT_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+}  // namespace vrt

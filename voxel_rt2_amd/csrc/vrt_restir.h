@@ -1,0 +1,333 @@
+// vrt_restir.h -- ReSTIR-PT: input reservoir construction, reconnection shift, spatial reuse.
+//
+// Replaces Sample / Reservoir / StorageReservoir (reference renderer/reservoir.py:8-141), the
+// reservoir part of Renderer.render (pathtracer.py:549-607, 620-626), Renderer.shift (672-812)
+// and Renderer.spatial_GRIS (815-989).  Only compiled into the RESTIR instantiation of the render
+// kernel and into the spatial-reuse kernel; with ReSTIR off (the reference default,
+// pathtracer.py:15) no reservoir is stored at all -- nothing reads it.
+//
+// Reference quirks kept: self.current_frame inside spatial_GRIS is the
+// value baked at first compile (0); angle_shift value-casts the u32 bit pattern; the jacobian
+// rejection test sits in the `jacobian = 0` branch.  Taps outside the image are skipped (the
+// reference reads out of bounds there).
+#ifndef VRT_RESTIR_H
+#define VRT_RESTIR_H
+
+#include "vrt_path.h"
+
+namespace vrt {
+
+struct RSample {
+    f3 F, rc_pos, rc_normal, rc_incident_dir, rc_incident_L, rc_nee_dir;
+    uint32_t rc_mat_info;
+    float jac;
+    int lobes;
+};
+struct Reservoir {
+    RSample z;
+    float M, weight;
+};
+
+VRT_DEV void reservoir_init(Reservoir& r) {  // reservoir.py:46-57
+    r.z.F = mk3(0.0f); r.z.rc_pos = mk3(0.0f); r.z.rc_normal = mk3(0.0f); r.z.rc_incident_dir = mk3(0.0f);
+    r.z.rc_incident_L = mk3(0.0f); r.z.rc_nee_dir = mk3(0.0f);
+    r.z.rc_mat_info = 0u; r.z.jac = 1.0f; r.z.lobes = 0;
+    r.M = 0.0f; r.weight = 0.0f;
+}
+VRT_DEV void reservoir_update_jacobian(Reservoir& r, f3 x1) {  // :59-62
+    f3 d = r.z.rc_pos - x1;
+    r.z.jac = dot3(d, d) / dm_abs(dot3(norm3(d), r.z.rc_normal));
+}
+// :64-74 (input_sample, in_M = 1) and :76-86 (merge, in_M = in_r.M)
+VRT_DEV bool reservoir_add(Reservoir& r, const RSample& z, float in_M, float in_w, dm_rng& rng, bool force_add) {
+    r.M += in_M;
+    bool selected = false;
+    if (in_w > 0.0f) {
+        r.weight += in_w;
+        bool lt = dm_rng_f32(&rng) * r.weight <= in_w;
+        selected = lt || force_add;
+        if (selected) r.z = z;
+    }
+    return selected;
+}
+VRT_DEV void reservoir_finalize_without_M(Reservoir& r) {  // :96-102
+    float p_hat = lum(r.z.F);
+    r.weight = (p_hat < 1e-6f) ? 0.0f : r.weight / p_hat;
+}
+VRT_DEV uint32_t pack4x8(float a, float b, float c, float d) {  // math_utils.py:250-255, sizes (8,8,8,8)
+    return dm_f2u32(a * 255.0f + 0.5f) | (dm_f2u32(b * 255.0f + 0.5f) << 8) | (dm_f2u32(c * 255.0f + 0.5f) << 16) |
+           (dm_f2u32(d * 255.0f + 0.5f) << 24);
+}
+VRT_DEV ReservoirRec reservoir_encode(const Reservoir& r) {  // reservoir.py:104-124
+    ReservoirRec e;
+    e.F = r.z.F;
+    e.rc_pos = r.z.rc_pos;
+    e.rc_incident_L = r.z.rc_incident_L;
+    uint32_t on = oct_encode(r.z.rc_normal), od = oct_encode(r.z.rc_nee_dir);
+    e.rc_normal_and_nee = pack4x8(dm_f16_to_f32((uint16_t)(on & 0xffffu)), dm_f16_to_f32((uint16_t)(on >> 16)),
+                                  dm_f16_to_f32((uint16_t)(od & 0xffffu)), dm_f16_to_f32((uint16_t)(od >> 16)));
+    e.rc_incident_dir = oct_encode(r.z.rc_incident_dir);
+    e.rc_mat_info = r.z.rc_mat_info;
+    e.M_W = (uint32_t)dm_f32_to_f16(r.M) | ((uint32_t)dm_f32_to_f16(r.weight) << 16);
+    e.jac_lobes = (uint32_t)dm_f32_to_f16(r.z.jac) | (((uint32_t)(int8_t)r.z.lobes & 0xffu) << 16);
+    e.pad[0] = 0u; e.pad[1] = 0u;
+    return e;
+}
+VRT_DEV void reservoir_decode(Reservoir& r, const ReservoirRec& e) {  // reservoir.py:126-141
+    r.M = dm_f16_to_f32((uint16_t)(e.M_W & 0xffffu));
+    r.weight = dm_f16_to_f32((uint16_t)(e.M_W >> 16));
+    r.z.F = e.F;
+    r.z.rc_pos = e.rc_pos;
+    uint32_t q = e.rc_normal_and_nee;
+    r.z.rc_normal = oct_decode_f((float)(q & 255u) / 255.0f, (float)((q >> 8) & 255u) / 255.0f);
+    r.z.rc_nee_dir = oct_decode_f((float)((q >> 16) & 255u) / 255.0f, (float)((q >> 24) & 255u) / 255.0f);
+    r.z.rc_incident_dir = oct_decode(e.rc_incident_dir);
+    r.z.rc_incident_L = e.rc_incident_L;
+    r.z.rc_mat_info = e.rc_mat_info;
+    r.z.jac = dm_f16_to_f32((uint16_t)(e.jac_lobes & 0xffffu));
+    r.z.lobes = (int)(int8_t)((e.jac_lobes >> 16) & 0xffu);
+}
+
+// pathtracer.py:549-607 and 620-626 (the USE_RESTIR_PT = True arm)
+template <class PathT>
+VRT_DEV void restir_finish(const FrameParams& fp, const SceneData& sc, const PixelBuffers& out, int local_idx, PathT& p,
+                           f3 primary_pos, f3& diffuse, f3& specular, TraceStats& ts) {
+    Reservoir r;
+    reservoir_init(r);
+    r.z.rc_pos = p.rs.rc_pos; r.z.rc_normal = p.rs.rc_normal; r.z.rc_incident_dir = p.rs.rc_incident_dir;
+    r.z.rc_incident_L = p.rs.rc_incident_L; r.z.rc_nee_dir = p.rs.rc_nee_dir; r.z.rc_mat_info = p.rs.rc_mat_info;
+    r.z.F = p.contrib;
+    r.z.lobes = p.rs.rc_lobe * 10 + p.first_lobe;
+    r.M = 1.0f;
+    reservoir_update_jacobian(r, primary_pos);
+    bool chose_nee = false;
+    if (!p.sky_primary) {
+        float bsdf_pdf = 1.0f / p.first_invpdf;
+        float light_pdf = cone_pdf(fp.light_cos_max, dot3(fp.light_dir, p.rs.first_dir));
+        if (near_zero3(p.nee_d + p.nee_s)) light_pdf = 0.0f;
+        float bsdf_mis = power_heuristic(bsdf_pdf, light_pdf);
+        float light_mis = power_heuristic(cone_pdf(fp.light_cos_max, 1.0f), p.rs.first_light_bsdf_pdf);
+        float p_hat = lum(r.z.F);
+        r.weight = bsdf_mis * p_hat * p.first_invpdf;
+        float light_w = light_mis * lum(p.nee_d + p.nee_s);
+        f3 sky_t = mk3(1.0f);
+        if (fp.use_sky == 1) { sky_t = sky_transmittance(sc.sky, p.rs.first_light_dir); ts.sky_lookups += 1u; }
+        RSample ls;
+        ls.F = p.nee_d + p.nee_s;
+        ls.rc_pos = p.rs.first_light_dir;
+        ls.rc_normal = mk3(0.0f); ls.rc_incident_dir = mk3(0.0f);
+        ls.rc_incident_L = sky_t * fp.light_weight * fp.light_color;
+        ls.rc_nee_dir = mk3(0.0f);
+        ls.rc_mat_info = 0u; ls.jac = 1.0f; ls.lobes = LOBE_ALL * 10 + LOBE_ALL;
+        chose_nee = reservoir_add(r, ls, 1.0f, light_w, p.rng, false);
+        reservoir_finalize_without_M(r);
+    } else {
+        r.weight = 1.0f;
+    }
+    out.reservoir[local_idx] = reservoir_encode(r);
+    if (!chose_nee) {
+        diffuse = diffuse + ((p.first_lobe == LOBE_DIFFUSE) ? r.z.F : mk3(0.0f));
+        specular = specular + ((p.first_lobe == LOBE_SPEC) ? r.z.F : mk3(0.0f));
+    } else {
+        diffuse = diffuse + p.nee_d;
+        specular = specular + p.nee_s;
+    }
+}
+
+VRT_DEV Material material_from_bits(const float* mats, uint32_t enc, int& id) {  // math_utils.py:238-247
+    id = (int)(enc & 255u);
+    Material m = load_material(mats, id);
+    m.base = unpack_albedo(enc);
+    return m;
+}
+
+// pathtracer.py:672-812: shift `src`'s sample to the primary vertex (dst_pos, dst_normal, dst_mat)
+VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, f3 dst_pos, f3 dst_normal, const Material& dst_mat,
+                          const Reservoir& src, f3& out_d, f3& out_s, float& out_jac, TraceStats& ts) {
+    const bool escape = near_zero3(src.z.rc_normal);
+    const bool last = near_zero3(src.z.rc_incident_dir);
+    const bool nee_vis = !near_zero3(src.z.rc_nee_dir);
+    const f3 to_rc = escape ? src.z.rc_pos : norm3(src.z.rc_pos - dst_pos);
+    float passed = 1.0f;
+    if (dot3(dst_normal, to_rc) < 1e-5f || (!escape && dot3(src.z.rc_normal, -to_rc) < 1e-5f)) passed = 0.0f;
+
+    int rc_id;
+    const Material rc_mat = material_from_bits(sc.mats, src.z.rc_mat_info, rc_id);
+    f3 contrib = mk3(0.0f);
+    if (!escape) {
+        Surf rc;
+        surf_init(rc, rc_mat, src.z.rc_normal, -to_rc);
+        if (!last) {
+            f3 bd, bs;
+            eval_lobes(rc, src.z.rc_incident_dir, src.z.lobes / 10, bd, bs);
+            f3 rc_brdf = (bd + bs) * dm_saturate(dot3(src.z.rc_normal, src.z.rc_incident_dir));
+            float dst_rc_pdf = pdf_lobe(rc, src.z.rc_incident_dir, src.z.lobes / 10);
+            float lp = cone_pdf(fp.light_cos_max, dot3(fp.light_dir, src.z.rc_incident_dir));
+            float w = power_heuristic(dst_rc_pdf, lp * (nee_vis ? 1.0f : 0.0f));
+            contrib = contrib + firefly(w * rc_brdf / dst_rc_pdf * src.z.rc_incident_L);
+        }
+        if (nee_vis) {
+            f3 bd, bs;
+            eval_lobes(rc, src.z.rc_nee_dir, LOBE_ALL, bd, bs);
+            f3 nee_brdf = (bd + bs) * dm_saturate(dot3(src.z.rc_normal, src.z.rc_nee_dir));
+            float w = power_heuristic(cone_pdf(fp.light_cos_max, 1.0f), pdf_all(rc, src.z.rc_nee_dir));
+            f3 sky_t = mk3(1.0f);
+            if (fp.use_sky == 1) { sky_t = sky_transmittance(sc.sky, src.z.rc_nee_dir); ts.sky_lookups += 1u; }
+            contrib = contrib + firefly(w * nee_brdf * sky_t * fp.light_weight * fp.light_color);
+        }
+    } else {
+        contrib = contrib + firefly(src.z.rc_incident_L);
+    }
+    contrib = contrib + ((rc_id != 2) ? mk3(0.0f) : rc_mat.base);
+
+    Surf ds;
+    surf_init(ds, dst_mat, dst_normal, norm3(fp.camera_pos - dst_pos));
+    f3 pd, ps;
+    eval_lobes(ds, to_rc, src.z.lobes % 10, pd, ps);
+    const float c = dm_saturate(dot3(dst_normal, to_rc));
+    pd = pd * c;
+    ps = ps * c;
+    out_d = pd * contrib;
+    out_s = ps * contrib;
+
+    float jac = 1.0f;
+    if (!escape) {
+        f3 dv = src.z.rc_pos - dst_pos;
+        jac = src.z.jac;
+        jac *= dm_abs(dot3(norm3(dv), src.z.rc_normal)) / dot3(dv, dv);
+    }
+    if (jac < 0.0f || dm_isnan(jac) || dm_isinf(jac)) {
+        jac = 0.0f;
+        if (dm_max(jac, 1.0f / jac) > 11.0f) { out_d = mk3(0.0f); out_s = mk3(0.0f); }
+    }
+    out_jac = jac * passed;
+}
+
+VRT_DEV uint32_t hash3(uint32_t x, uint32_t y, uint32_t z) {  // math_utils.py:217-229
+    x += x >> 11; x ^= x << 7; x += y; x ^= x << 3; x += z ^ (x >> 14);
+    x ^= x << 6; x += x >> 15; x ^= x << 5; x += x >> 12; x ^= x << 9;
+    return x;
+}
+
+struct GrisBuffers {
+    const f3* color_d_in;
+    const f3* color_s_in;
+    f3* color_d_out;
+    f3* color_s_out;
+    const uint32_t* gb_normal;
+    const float* gb_depth;
+    const uint32_t* gb_mat;
+    const ReservoirRec* res_in;
+    ReservoirRec* res_out;
+};
+
+// pathtracer.py:815-989, called as spatial_GRIS(0, 24.0, 32, 1) (:1313)
+template <class PyrT>
+VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& P, const GrisBuffers& gb, int u, int v,
+                        int pass_id, float max_radius, int max_taps, int pass_total, TraceStats& ts) {
+    if (outside_render_area(fp, (float)u, (float)v)) return;
+    const int idx = (v - fp.row0) * fp.W + u;
+    dm_rng rng = dm_rng_init(fp.seed, fp.frame, (uint32_t)(v * fp.W + u), 1u);
+    const f2 tc = pixel_texcoord(fp, (float)u, (float)v);
+    (void)dm_rng_f32(&rng);  // start_index draw (:827), value unused
+    const uint32_t sx = (pass_id == 0) ? ((uint32_t)u >> 3) : 2u, sy = (pass_id == 0) ? ((uint32_t)v >> 3) : 2u;
+    const uint32_t hs = hash3(sx, sy, 0u + (uint32_t)pass_id);
+    const float angle_shift = (float)((hs & 0x007FFFFFu) | 0x3F800000u) / 4294967295.0f * DM_PI;
+    const float radius_shift = dm_rng_f32(&rng);
+
+    Reservoir center, outr;
+    reservoir_init(center);
+    reservoir_decode(center, gb.res_in[idx]);
+    reservoir_init(outr);
+
+    const float cdepth = gb.gb_depth[idx];
+    const f3 cx1 = xform(fp.view_inv, screen_to_view(tc, cdepth, fp.proj_inv), 1.0f);
+    const float cdist = len3(cx1 - fp.camera_pos);
+    const f3 cn1 = oct_decode(gb.gb_normal[idx]);
+    if (near_zero3(cx1)) {
+        gb.color_d_out[idx] = center.z.F;
+        gb.color_s_out[idx] = gb.color_s_in[idx];
+        gb.res_out[idx] = gb.res_in[idx];
+        return;
+    }
+    int cmat_id;
+    const Material cmat = material_from_bits(sc.mats, gb.gb_mat[idx], cmat_id);
+    int valid = 0;
+    float canonical_mis = 1.0f;
+    f3 chosen_d = mk3(0.0f), chosen_s = mk3(0.0f);
+
+    for (int i = 0; i < max_taps; i++) {
+        const float golden = 2.399963229728f;
+        float angle = ((float)i + angle_shift) * golden;
+        float rad = dm_sqrt(((float)i + radius_shift) / (float)max_taps) * max_radius;
+        float sa, ca;
+        dm_sincos(angle, &sa, &ca);
+        int ox = dm_f2i(ca * rad), oy = dm_f2i(sa * rad);
+        if (ox == 0 && oy == 0) continue;
+        int tx = u + ox, ty = v + oy;
+        if (tx < 0 || ty < 0 || tx >= fp.W || ty >= fp.H) continue;
+        const int t = (ty - fp.row0) * fp.W + tx;
+        const f2 ttc = pixel_texcoord(fp, (float)tx, (float)ty);
+        const f3 nn1 = oct_decode(gb.gb_normal[t]);
+        const f3 nx1 = xform(fp.view_inv, screen_to_view(ttc, gb.gb_depth[t], fp.proj_inv), 1.0f);
+        const float ndist = len3(nx1 - fp.camera_pos);
+        Reservoir nb;
+        reservoir_init(nb);
+        reservoir_decode(nb, gb.res_in[t]);
+        if (dm_abs(ndist - cdist) > 0.1f * cdist || dot3(cn1, nn1) < 0.5f) continue;
+        int nmat_id;
+        const Material nmat = material_from_bits(sc.mats, gb.gb_mat[t], nmat_id);
+
+        f3 cd, cs, sd, ss;
+        float cjac, jac;
+        shift_sample(fp, sc, nx1, nn1, nmat, center, cd, cs, cjac, ts);
+        shift_sample(fp, sc, cx1, cn1, cmat, nb, sd, ss, jac, ts);
+
+        float c_p_hat = lum(cd + cs) * cjac;
+        float cw = c_p_hat * nb.M;
+        cw /= c_p_hat * nb.M + lum(center.z.F) * center.M / (float)max_taps;
+        canonical_mis += 1.0f - cw;
+
+        float p_hat = lum(sd + ss);
+        float p_hat_n = p_hat / jac;
+        float nw = p_hat_n * nb.M;
+        nw /= p_hat_n * nb.M + p_hat * center.M / (float)max_taps;
+        if (dm_isinf(nw) || dm_isnan(nw)) nw = 0.0f;
+
+        nb.z.F = sd + ss;
+        if (reservoir_add(outr, nb.z, nb.M, nb.weight * p_hat * jac * nw, rng, false)) { chosen_d = sd; chosen_s = ss; }
+        valid += 1;
+    }
+
+    // visibility of the chosen sample's reconnection (:959-967)
+    bool force_canonical = false;
+    const bool out_escape = near_zero3(outr.z.rc_normal);
+    const f3 to_rc = out_escape ? outr.z.rc_pos : norm3(outr.z.rc_pos - cx1);
+    Hit sh;
+    next_hit<true>(fp, sc, P, cx1 + cn1 * 0.003f * cdist, to_rc, sh, ts);
+    const float actual = out_escape ? DM_INF : len3(cx1 - outr.z.rc_pos);
+    if (sh.closest < DM_INF && dm_abs(sh.closest - actual) > 0.1f * actual) { outr.weight = 0.0f; force_canonical = true; }
+
+    if (reservoir_add(outr, center.z, center.M, center.weight * lum(center.z.F) * canonical_mis, rng, force_canonical)) {
+        chosen_d = gb.color_d_in[idx];
+        chosen_s = gb.color_s_in[idx];
+    }
+    reservoir_finalize_without_M(outr);
+    outr.weight /= (float)(valid + 1);
+
+    f3 od = gb.color_d_in[idx], os = gb.color_s_in[idx];
+    if (pass_id == pass_total - 1) {
+        f3 emission = (cmat_id == 2) ? cmat.base : mk3(0.0f);
+        if (fp.camera_is_moving == 1) chosen_d = chosen_d / max3s(cmat.base, 1e-2f);
+        float wc = dm_clamp(outr.weight, 0.0f, 50.0f);
+        od = chosen_d * wc + emission;
+        os = chosen_s * wc;
+    }
+    gb.color_d_out[idx] = od;
+    gb.color_s_out[idx] = os;
+    reservoir_update_jacobian(outr, cx1);
+    gb.res_out[idx] = reservoir_encode(outr);
+}
+
+}  // namespace vrt
+#endif

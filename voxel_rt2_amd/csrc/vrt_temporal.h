@@ -1,0 +1,207 @@
+// vrt_temporal.h -- temporal accumulation, one fused pass per pixel.
+//
+// Replaces Renderer.temporal_filter_prepass, temporal_filter, temporal_filter_specular and the
+// trailing copy loop (reference renderer/pathtracer.py:1020-1075, 1077-1130, 1132-1183,
+// 1185-1230, 1242-1303).  The reference launches three kernels plus a copy loop and moves about
+// 440 B per pixel per sample through HBM; fused, a static-camera sample reads the two colour
+// values (+ the bilinear neighbours, which hit L2), two 16-byte histories and writes the two
+// histories and the 12-byte HDR pixel.  The copy loop is replaced by swapping the in/out history
+// and current/previous g-buffer pointers on the host.
+//
+// Ordering semantics kept from the reference's kernel sequence: the NaN/Inf/negative scrub of the
+// prepass is applied to every colour tap as it is loaded (the prepass finishes before the filters
+// start), neighbour reads see the values the render stage wrote (snapshot), a pixel whose
+// reconstructed world position is ~0 is skipped by both filters and keeps its history.
+// Dead outputs of the reference are not produced (specular_mean/stdev, specular depth history).
+#ifndef VRT_TEMPORAL_H
+#define VRT_TEMPORAL_H
+
+#include "vrt_path.h"
+
+namespace vrt {
+
+struct TemporalBuffers {
+    const f3* color_d;
+    const f3* color_s;
+    const uint32_t* gb_normal;
+    const float* gb_depth;
+    const uint32_t* gb_mat;
+    const float* gb_refl_raw;
+    float* gb_refl_filtered;      // gbuff_depth_reflection after the prepass
+    const f4* hist_d_in;
+    f4* hist_d_out;
+    const f4* hist_s_in;
+    f4* hist_s_out;
+    const uint32_t* prev_normal;  // gbuff_prev_normals / gbuff_prev_depth
+    const float* prev_depth;
+    f3* hdr;                      // color_buffer after accumulate()
+};
+
+VRT_DEV f3 scrub(f3 c) {  // pathtracer.py:1069-1075
+    bool bad = dm_isnan(c.x) || dm_isinf(c.x) || c.x < 0.0f || dm_isnan(c.y) || dm_isinf(c.y) || c.y < 0.0f ||
+               dm_isnan(c.z) || dm_isinf(c.z) || c.z < 0.0f;
+    return bad ? mk3(0.0f) : c;
+}
+VRT_DEV void render_res(const FrameParams& fp, int& rx, int& ry) {
+    rx = dm_f2i((float)fp.W * fp.render_scale);
+    ry = dm_f2i((float)fp.H * fp.render_scale);
+}
+// local index of global pixel (x, y), clamped to the image (bilinear taps past the edge)
+VRT_DEV int clamped_index(const FrameParams& fp, int x, int y) {
+    x = x < 0 ? 0 : (x > fp.W - 1 ? fp.W - 1 : x);
+    y = y < 0 ? 0 : (y > fp.H - 1 ? fp.H - 1 : y);
+    return (y - fp.row0) * fp.W + x;
+}
+// pathtracer.py:1077-1090 on a scrubbed colour buffer
+VRT_DEV f3 bilinear_color(const FrameParams& fp, const f3* buf, f2 uv) {
+    int rx, ry;
+    render_res(fp, rx, ry);
+    float fcx = uv.x * (float)rx - 0.5f, fcy = uv.y * (float)ry - 0.5f;
+    int ix = dm_f2i(fcx), iy = dm_f2i(fcy);
+    float fx = frac1(fcx), fy = frac1(fcy);
+    f3 bl = scrub(buf[clamped_index(fp, ix, iy)]), br = scrub(buf[clamped_index(fp, ix + 1, iy)]);
+    f3 tl = scrub(buf[clamped_index(fp, ix, iy + 1)]), tr = scrub(buf[clamped_index(fp, ix + 1, iy + 1)]);
+    return lerp3(lerp3(bl, br, fx), lerp3(tl, tr, fx), fy);
+}
+VRT_DEV f3 reproject(const FrameParams& fp, f3 wp) {  // pathtracer.py:993-1000
+    f4 p = mul4(fp.prev_proj, mul4(fp.prev_view, mk4(wp.x, wp.y, wp.z, 1.0f)));
+    return mk3(p.x / p.w, p.y / p.w, p.z / p.w) * 0.5f + 0.5f;
+}
+VRT_DEV float catmullrom(float x) {  // pathtracer.py:1002-1014
+    float x2 = x * x, x3 = x * x * x, fx = 0.0f;
+    if (x < 1.0f) fx = 1.5f * x3 - 2.5f * x2 + 1.0f;
+    else if (x < 2.0f) fx = -0.5f * x3 + 2.5f * x2 - 4.0f * x + 2.0f;
+    return fx;
+}
+// pathtracer.py:1092-1130 (DEPTH_TEST) and 1132-1183 (without): 4x4 Catmull-Rom history resample
+template <bool DEPTH_TEST>
+VRT_DEV float history_resample(const FrameParams& fp, const TemporalBuffers& tb, const f4* hist, f2 uv, float center_depth,
+                               f3 center_normal, f4& out) {
+    int rx, ry;
+    render_res(fp, rx, ry);
+    float fcx = uv.x * (float)rx - 0.5f, fcy = uv.y * (float)ry - 0.5f;
+    int icx = dm_f2i(fcx), icy = dm_f2i(fcy);
+    float fx = frac1(fcx), fy = frac1(fcy);
+    float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, mx[4] = {0.0f, 0.0f, 0.0f, 0.0f}, mn[4] = {999999.0f, 999999.0f, 999999.0f, 999999.0f};
+    float wsum = 0.0f;
+    for (int x = -1; x < 3; x++)
+        for (int y = -1; y < 3; y++) {
+            int tx = icx + x, ty = icy + y;
+            if (tx < 0 || ty < 0 || tx > rx - 1 || ty > ry - 1) continue;
+            int t = (ty - fp.row0) * fp.W + tx;
+            float w = catmullrom(dm_abs((float)x - fx)) * catmullrom(dm_abs((float)y - fy));
+            f3 tn = oct_decode(tb.prev_normal[t]);
+            if (fp.camera_is_moving == 1) {
+                if (DEPTH_TEST) {
+                    float td = linearize_depth(tb.prev_depth[t], fp.proj_inv);
+                    w *= (dm_abs(td - center_depth) / center_depth < 0.05f) ? 1.0f : 0.0f;
+                }
+                w *= (dot3(center_normal, tn) > 0.642f) ? 1.0f : 0.0f;
+            }
+            f4 c = hist[t];
+            float cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                mx[k] = dm_max(mx[k], cv[k]);
+                mn[k] = dm_min(mn[k], cv[k]);
+                sum[k] += cv[k] * w;
+            }
+            wsum += w;
+        }
+    out.x = dm_max(dm_clamp(sum[0] / wsum, mn[0], mx[0]), 0.0f);
+    out.y = dm_max(dm_clamp(sum[1] / wsum, mn[1], mx[1]), 0.0f);
+    out.z = dm_max(dm_clamp(sum[2] / wsum, mn[2], mx[2]), 0.0f);
+    out.w = dm_max(dm_clamp(sum[3] / wsum, mn[3], mx[3]), 1.0f);
+    return wsum;
+}
+
+VRT_DEV void blend_history(const FrameParams& fp, float wsum, f4& h, f3 cur) {  // :1216-1220, 1283-1289
+    if (wsum > 1e-3f) {
+        h.w = dm_min(h.w + 1.0f, fp.max_accum_frames);
+        f3 m = lerp3(mk3(h.x, h.y, h.z), cur, 1.0f / h.w);
+        h.x = m.x; h.y = m.y; h.z = m.z;
+    } else {
+        h = mk4(cur.x, cur.y, cur.z, 1.0f);
+    }
+}
+
+// One pixel (u, v) of this shard's rows.
+VRT_DEV void temporal_pixel(const FrameParams& fp, const TemporalBuffers& tb, int u, int v) {
+    if (outside_render_area(fp, (float)u, (float)v)) return;
+    const int idx = (v - fp.row0) * fp.W + u;
+    int rx, ry;
+    render_res(fp, rx, ry);
+
+    // prepass: reflection-depth average over the valid taps of a 4x4 window (:1040-1066)
+    float rsum = 0.0f, rcount = 0.0f;
+    for (int x = -1; x < 3; x++)
+        for (int y = -1; y < 3; y++) {
+            int tx = u + x, ty = v + y;
+            if (tx < 0 || ty < 0 || tx > rx - 1 || ty > ry - 1) continue;
+            if (ty < fp.row0 || ty >= fp.row1) continue;  // beyond the shard's halo (reflection depth is unused there)
+            float rd = tb.gb_refl_raw[(ty - fp.row0) * fp.W + tx];
+            if (rd != 0.0f) { rcount += 1.0f; rsum += rd; }
+        }
+    const float refl_depth = (rcount > 0.01f) ? rsum / rcount : 0.0f;
+    tb.gb_refl_filtered[idx] = refl_depth;
+
+    const f2 tc = pixel_texcoord(fp, (float)u, (float)v);
+    const float nl_depth = tb.gb_depth[idx];
+    const f3 x1 = xform(fp.view_inv, screen_to_view(tc, nl_depth, fp.proj_inv), 1.0f);
+    if (near_zero3(x1)) {  // both filters `continue`: colour stays the scrubbed diffuse sample, histories persist
+        tb.hdr[idx] = scrub(tb.color_d[idx]);
+        tb.hist_d_out[idx] = tb.hist_d_in[idx];
+        tb.hist_s_out[idx] = tb.hist_s_in[idx];
+        return;
+    }
+    const f3 cur_d = bilinear_color(fp, tb.color_d, tc);
+    const f3 cur_s = bilinear_color(fp, tb.color_s, tc);
+    f4 hd, hs;
+    float wd = 1.0f, ws = 1.0f;
+    if (fp.camera_is_moving == 0) {
+        hd = tb.hist_d_in[idx];
+        hs = tb.hist_s_in[idx];
+    } else {
+        const f3 n1 = oct_decode(tb.gb_normal[idx]);
+        f3 rp = reproject(fp, x1);
+        wd = history_resample<true>(fp, tb, tb.hist_d_in, mk2(rp.x, rp.y), linearize_depth(rp.z, fp.proj_inv), n1, hd);
+        float nl = delinearize_depth(refl_depth, fp.proj);
+        f3 refl_pos = xform(fp.view_inv, screen_to_view(tc, nl, fp.proj_inv), 1.0f);
+        f3 rps = reproject(fp, (refl_depth != 0.0f) ? refl_pos : x1);
+        ws = history_resample<false>(fp, tb, tb.hist_s_in, mk2(rps.x, rps.y), linearize_depth(rps.z, fp.proj_inv), n1, hs);
+    }
+    blend_history(fp, wd, hd, cur_d);
+    blend_history(fp, ws, hs, cur_s);
+    tb.hist_d_out[idx] = hd;
+    tb.hist_s_out[idx] = hs;
+    f3 col = mk3(hd.x, hd.y, hd.z);
+    if (fp.camera_is_moving == 1) col = col * unpack_albedo(tb.gb_mat[idx]);  // re-modulate albedo (:1227-1228)
+    tb.hdr[idx] = col + mk3(hs.x, hs.y, hs.z);
+}
+
+// Renderer._render_to_image (pathtracer.py:634-662) with uchimura (math_utils.py:163-186)
+VRT_DEV float uchimura1(float x) {
+    const double P = 1.0, a = 1.0, m = 0.22, l = 0.4, c = 1.33, b = 0.0;
+    const double l0 = ((P - m) * l) / a, S0 = m + l0, S1 = m + a * l0, C2 = (a * P) / (P - S1), CP = -C2 / P;
+    float t0 = dm_clamp((x - 0.0f) / ((float)m - 0.0f), 0.0f, 1.0f);
+    float w0 = 1.0f - t0 * t0 * (3.0f - 2.0f * t0);
+    float w2 = (x < (float)(m + l0)) ? 0.0f : 1.0f;
+    float w1 = 1.0f - w0 - w2;
+    float T = (float)m * dm_pow(x / (float)m, (float)c) + (float)b;
+    float S = (float)P - (float)(P - S1) * dm_exp((float)CP * (x - (float)S0));
+    float L = (float)m + (float)a * (x - (float)m);
+    return T * w0 + L * w1 + S * w2;
+}
+VRT_DEV f4 tonemap_pixel(const FrameParams& fp, const f3* hdr, int i, int j) {
+    float ux = (float)i / (float)fp.W, uy = (float)j / (float)fp.H;
+    float dx = ux - 0.5f, dy = uy - 0.5f;
+    float darken = 1.0f - 0.9f * dm_max(dm_sqrt(dx * dx + dy * dy) - 0.0f, 0.0f);
+    int sx = dm_f2i((float)i * fp.render_scale), sy = dm_f2i((float)j * fp.render_scale);
+    f3 c = hdr[(sy - fp.row0) * fp.W + sx] * darken * fp.exposure;
+    const float g = (float)(1.0 / 2.2);
+    return mk4(dm_saturate(dm_pow(uchimura1(c.x), g)), dm_saturate(dm_pow(uchimura1(c.y), g)),
+               dm_saturate(dm_pow(uchimura1(c.z), g)), 1.0f);
+}
+
+}  // namespace vrt
+#endif

@@ -1,0 +1,126 @@
+// vrt_types.h -- device-side vector types and the kernel parameter block of libvrt_hip.so.
+//
+// Everything under csrc/ is written for gfx950 (MI355X, wave64).  The headers also compile as
+// plain C++ (VRT_DEV becomes `inline`) so that the CPU sanitizer / emulation build used by the
+// test-suite can step the same per-path functions without a GPU; that build is test tooling,
+// the shipped library has no CPU path.
+#ifndef VRT_TYPES_H
+#define VRT_TYPES_H
+
+#include <stdint.h>
+#include "../../include/vrt_detmath.h"
+
+#if defined(__HIPCC__)
+#define VRT_DEV __host__ __device__ __forceinline__
+#define VRT_DEV_NOINLINE __device__ __noinline__
+#else
+#define VRT_DEV inline
+#define VRT_DEV_NOINLINE inline
+#endif
+
+namespace vrt {
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+struct i3 { int x, y, z; };
+
+VRT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+VRT_DEV f3 mk3(float s) { return mk3(s, s, s); }
+VRT_DEV f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+VRT_DEV f4 mk4(float x, float y, float z, float w) { f4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+
+VRT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+VRT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+VRT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+VRT_DEV f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+VRT_DEV f3 operator+(f3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
+VRT_DEV f3 operator-(f3 a, float s) { return mk3(a.x - s, a.y - s, a.z - s); }
+VRT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+VRT_DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+VRT_DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+VRT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+VRT_DEV float comp(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// sums are left to right; nothing here may be contracted into an fma (-ffp-contract=off)
+VRT_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+VRT_DEV f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+VRT_DEV float len3(f3 a) { return dm_sqrt(dot3(a, a)); }
+VRT_DEV f3 norm3(f3 a) { float inv = 1.0f / len3(a); return inv * a; }
+VRT_DEV f3 abs3(f3 a) { return mk3(dm_abs(a.x), dm_abs(a.y), dm_abs(a.z)); }
+VRT_DEV f3 floor3(f3 a) { return mk3(dm_floor(a.x), dm_floor(a.y), dm_floor(a.z)); }
+VRT_DEV f3 clamp3(f3 a, float lo, float hi) { return mk3(dm_clamp(a.x, lo, hi), dm_clamp(a.y, lo, hi), dm_clamp(a.z, lo, hi)); }
+VRT_DEV f3 max3s(f3 a, float s) { return mk3(dm_max(a.x, s), dm_max(a.y, s), dm_max(a.z, s)); }
+VRT_DEV f3 sat3(f3 a) { return mk3(dm_saturate(a.x), dm_saturate(a.y), dm_saturate(a.z)); }
+VRT_DEV float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+VRT_DEV float lerp1(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+VRT_DEV f3 lerp3(f3 x, f3 y, float a) { return x * (1.0f - a) + y * a; }
+VRT_DEV float frac1(float x) { return x - dm_floor(x); }
+VRT_DEV float sq(float x) { return x * x; }
+VRT_DEV bool near_zero3(f3 v) { return dot3(v, v) < 1e-7f; }
+VRT_DEV float lum(f3 c) { return dot3(mk3(0.2125f, 0.7154f, 0.0721f), c); }
+VRT_DEV f3 firefly(f3 v) { return clamp3(v, 0.0f, 300.0f); }
+
+struct mat4 { float m[16]; };  // row-major, m[row*4+col]
+VRT_DEV f4 mul4(const mat4& M, f4 v) {
+    return mk4(M.m[0] * v.x + M.m[1] * v.y + M.m[2] * v.z + M.m[3] * v.w,
+               M.m[4] * v.x + M.m[5] * v.y + M.m[6] * v.z + M.m[7] * v.w,
+               M.m[8] * v.x + M.m[9] * v.y + M.m[10] * v.z + M.m[11] * v.w,
+               M.m[12] * v.x + M.m[13] * v.y + M.m[14] * v.z + M.m[15] * v.w);
+}
+
+#define VRT_EPS 1e-6f
+#define VRT_GRID 128
+
+// One Disney material row (14 f32, the order of the host table).
+struct Material {
+    f3 base;
+    float subsurface, metallic, specular, specular_tint, roughness, anisotropic, sheen, sheen_tint, clearcoat,
+        clearcoat_gloss, ior_minus_one;
+};
+
+// Traversal counters of the instrumented build (one slot per counter, atomically summed).
+struct Counters { unsigned long long rays, iters, queries, closest_hits, sky_lookups; };
+
+// Occupancy pyramid as three levels of 4x4x4 bit bricks (64-bit words):
+//   l0[32^3]: bit = voxel solid          -> LOD 0 (bit), LOD 1 (2x2x2 sub-mask), LOD 2 (word != 0)
+//   l1[ 8^3]: bit = l0 word non-zero     -> LOD 2 (bit), LOD 3 (sub-mask),       LOD 4 (word != 0)
+//   l2[ 2^3]: bit = l1 word non-zero     -> LOD 4 (bit), LOD 5 (sub-mask),       LOD 6 (word != 0)
+// Word index inside a level: (bz * n + by) * n + bx; bit inside a word: (z&3)*16 + (y&3)*4 + (x&3).
+struct Pyramid {
+    const unsigned long long* l0;
+    const unsigned long long* l1;
+    const unsigned long long* l2;
+};
+
+struct SkyTables {
+    const float* scattering;     // [res][res][3]
+    const float* transmittance;  // [res][res][3]
+    int res;
+    float fres;
+};
+
+// Everything the per-pixel kernels read that is not a per-pixel buffer.  Passed by value.
+struct FrameParams {
+    mat4 view, proj, view_inv, proj_inv, prev_view, prev_proj;
+    f3 camera_pos;
+    f2 taa_jitter;
+    f2 inv_res;
+    int W, H;
+    int row0, row1;             // rows rendered by this launch (shard + halo)
+    int camera_is_moving;
+    float render_scale, max_accum_frames;
+    f3 light_dir, light_color;
+    float light_cos_max, light_weight;
+    float floor_height;
+    f3 floor_color;
+    int floor_material;
+    f3 background;
+    int use_sky;
+    float voxel_edges, exposure;
+    int max_depth;
+    uint32_t seed, frame;
+};
+
+}  // namespace vrt
+#endif
