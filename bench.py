@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: Mpath-samples/s of Renderer.accumulate() on MI355X.
+
+Workload (BASELINE.json configs[1]): example-1-style scene S1 on the 128^3 grid, 1920x1080,
+4 spp per frame, 8 bounces.  One "step" = one frame = 4 accumulate() passes over every pixel;
+a path-sample = one pixel x one pass.  All inputs are resident in HBM
+before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by the driver through torch.distributed.run, one rank per GPU: the frame is
+split into N contiguous row tiles (strong scaling: the frame is fixed), every rank renders its
+tile with no data-path communication, and the HDR tiles are gathered to rank 0 over RCCL at the
+end of every step (inside the timed region).
+
+Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel (k_render)
+and the CPU-oracle baseline timed on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+WIDTH, HEIGHT, SPP_PER_STEP, MAX_DEPTH, SEED = 1920, 1080, 4, 8, 0
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def split_rows(height, n):
+    edges = [(height * i) // n for i in range(n + 1)]
+    return [(edges[i], edges[i + 1]) for i in range(n)]
+
+
+def setup_session(sess, mat, rgb, params):
+    from voxel_rt2_amd import host, materials
+    sess.upload_voxels(mat, rgb)
+    sess.upload_materials(materials.load_table())
+    sess.set_scene(host.make_scene_params(**params))
+    sess.set_camera(host.default_camera(sess.W, sess.H, jitter_index=1))
+    sess.prepare()
+
+
+def cpu_baseline(mat, rgb, params):
+    """The CPU oracle (oracle/, a restatement of the reference's ti.cpu path) on a bounded sample
+    of the same workload: a central band of rows of the same frame, same depth / spp / seed."""
+    import orc
+    from voxel_rt2_amd import host
+    cores = os.cpu_count() or 1
+    rows = (HEIGHT // 2 - 96, HEIGHT // 2 + 96)
+    cfg = host.make_config(WIDTH, HEIGHT, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=MAX_DEPTH,
+                           seed=SEED, rows=rows)
+    o = orc.Oracle(cfg, threads=cores)
+    setup_session(o, mat, rgb, params)
+    t0 = time.perf_counter()
+    o.accumulate(SPP_PER_STEP)
+    dt = time.perf_counter() - t0
+    samples = WIDTH * (rows[1] - rows[0]) * SPP_PER_STEP
+    hdr = o.fetch_hdr()[rows[0]:rows[1]]
+    o.close()
+    return dict(value=samples / dt / 1e6, unit="Mpath-samples/s", cores=cores, kind="port",
+                sample=f"rows {rows[0]}-{rows[1]} of the {WIDTH}x{HEIGHT} frame, {SPP_PER_STEP} spp, {MAX_DEPTH} bounces "
+                       f"({samples} path-samples, {dt:.1f} s)"), hdr, rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from voxel_rt2_amd import host, scenes, _lib
+    from voxel_rt2_amd._session import NativeSession
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the renderer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    mat, rgb, params = scenes.scene_s1(0)
+    rows = split_rows(HEIGHT, world)[rank]
+    cfg = host.make_config(WIDTH, HEIGHT, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=MAX_DEPTH,
+                           seed=SEED, device=local_rank, rows=rows if world > 1 else None)
+    lib = _lib.load()
+    sess = NativeSession(lib, "vrt_", cfg)
+    setup_session(sess, mat, rgb, params)
+
+    # gather plumbing: equal-sized tiles (padded to the tallest tile), torch owns the staging tensors
+    max_rows = max(b - a for a, b in split_rows(HEIGHT, world))
+    tile = torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device="cuda")
+    gathered = [torch.zeros_like(tile) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        sess.accumulate(SPP_PER_STEP)
+        if world > 1:
+            sess.fetch_hdr_device(tile.data_ptr())  # D2D on the library's stream, returns when done
+            dist.gather(tile, gathered, dst=0)
+
+    def fence():
+        sess.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    lib.vrt_reset_stats(C.c_void_p(sess._ctx))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = sess.stats()
+
+    # algorithmic bytes of the dominant kernel: one untimed instrumented pass counts what a path does
+    lib.vrt_set_instrumented(C.c_void_p(sess._ctx), 1)
+    lib.vrt_reset_stats(C.c_void_p(sess._ctx))
+    sess.accumulate(SPP_PER_STEP)
+    ist = sess.stats()
+    lib.vrt_set_instrumented(C.c_void_p(sess._ctx), 0)
+
+    if rank == 0:
+        total_samples = WIDTH * HEIGHT * SPP_PER_STEP * args.steps
+        value = total_samples / elapsed / 1e6
+        own_px = WIDTH * (rows[1] - rows[0])
+        # per path-sample counts on this rank's tile (SURVEY.md section 8d formula, render-kernel share):
+        # 4 B per occupancy query + (4 B texel + 56 B material row) per closest hit + 96 B per sky lookup
+        # + 52 B written per path (two colour values and the g-buffer)
+        n_inst = max(ist["path_samples"], 1)
+        q, hc, ls = ist["occupancy_queries"] / n_inst, ist["closest_hits"] / n_inst, ist["sky_lookups"] / n_inst
+        bytes_per_sample = 4.0 * q + 60.0 * hc + 96.0 * ls + 52.0
+        launches = max(st["render_launches"], 1)
+        avg_ms = st["render_ms"] / launches
+        achieved = bytes_per_sample * own_px / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("k_render_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpath-samples/sec at 1920x1080, 8 bounces", "value": round(value, 3), "unit": "Mpath-samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "example1-style scene S1 (scenes.scene_s1), 128^3 grid, 1920x1080, 4 spp/step, 8 bounces, "
+                                   "static camera, ReSTIR off", "width": WIDTH, "height": HEIGHT, "spp_per_step": SPP_PER_STEP,
+                       "max_depth": MAX_DEPTH, "seed": SEED, "sharding": f"{world} contiguous row tile(s) + RCCL gather" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "kernel": "k_render", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "algorithmic_bytes_per_path_sample": round(bytes_per_sample, 2),
+                         "queries_per_path_sample": round(q, 2), "closest_hits_per_path_sample": round(hc, 3),
+                         "render_ms_per_launch": round(avg_ms, 4),
+                         "temporal_ms_per_launch": round(st["temporal_ms"] / max(st["temporal_launches"], 1), 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cb, ref_rows, rr = cpu_baseline(mat, rgb, params)
+            out["cpu_baseline"] = cb
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    sess.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -242,7 +242,7 @@ DM_HD uint16_t dm_f32_to_f16(float f) {
     uint32_t u = dm_f2u(f);
     uint32_t sign = (u >> 16) & 0x8000u;
     uint32_t a = u & 0x7fffffffu;
-    if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);            /* NaN */
+    if (a > 0x7f800000u) return (uint16_t)0x7e00u;   /* NaN: one canonical code (0/0 is -NaN on x86, +NaN on gfx950) */
     if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);           /* >= 65520 -> inf */
     if (a < 0x33000001u) return (uint16_t)sign;                        /* <= 2^-25 -> 0 */
     if (a < 0x38800000u) {                                             /* subnormal half */

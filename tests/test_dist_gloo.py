@@ -1,0 +1,77 @@
+"""The N > 1 path on CPU: world_size-2 (and 3) gloo process groups shard the frame by rows, each
+rank renders ITS rows (here with the CPU oracle standing in for a GPU context -- the sharding
+contract, halo handling and gather plumbing are the same code bench.py uses), rank 0 gathers and
+compares with the unsharded frame bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, SPP = 96, 50, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, restir, out_path):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import orc
+    from voxel_rt2_amd import host, scenes, parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mat, rgb, params = scenes.scene_sunlit(0)
+    rows = parallel.split_rows(H, world)[rank]
+    cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=5, seed=4,
+                           use_restir=restir, rows=rows)
+    o = orc.Oracle(cfg, threads=1)
+    orc.setup(o, mat, rgb, params)
+    o.accumulate(SPP)
+    hdr = o.fetch_hdr()
+    tile = torch.zeros((parallel.max_tile_rows(H, world), W, 3), dtype=torch.float32)
+    tile[: rows[1] - rows[0]] = torch.from_numpy(hdr[rows[0]:rows[1]])
+    frame = parallel.gather_frame(tile, H, W, rank, world)
+    if rank == 0:
+        np.save(out_path, frame.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,restir", [(2, False), (3, False), (2, True)])
+def test_sharded_frame_equals_full_frame(tmp_path, world, restir):
+    import orc
+    from voxel_rt2_amd import host, scenes
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), restir, out), nprocs=world, join=True)
+    got = np.load(out)
+    mat, rgb, params = scenes.scene_sunlit(0)
+    cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=5, seed=4, use_restir=restir)
+    o = orc.Oracle(cfg, threads=2)
+    orc.setup(o, mat, rgb, params)
+    o.accumulate(SPP)
+    ref = o.fetch_hdr()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_split_rows_covers_frame():
+    from voxel_rt2_amd import parallel
+    for h in (1080, 2160, 50, 7):
+        for n in (1, 2, 3, 4, 8):
+            parts = parallel.split_rows(h, n)
+            assert parts[0][0] == 0 and parts[-1][1] == h
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(n - 1))
+            assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
+    assert parallel.split_rows(1080, 8)[3] == (405, 540)  # 135-row tiles at 1080p

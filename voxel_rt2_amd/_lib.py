@@ -13,6 +13,32 @@ class LibraryMissing(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  Two HIP runtimes in
+    one process cannot both own the device (the second sees no GPU), and torch.distributed (RCCL)
+    lives in torch's.  So if torch is installed, map ITS runtime before libvrt_hip.so is loaded:
+    the loader then resolves our DT_NEEDED libamdhip64.so.7 to it by SONAME, and a later
+    `import torch` finds its library already mapped.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load(build_if_missing=True):
     global _lib
     if _lib is not None:
@@ -22,6 +48,7 @@ def load(build_if_missing=True):
             raise LibraryMissing(f"{SO_PATH} not found; run `python -m voxel_rt2_amd.build` (needs hipcc)")
         from . import build
         build.build()
+    _share_hip_runtime_with_torch()
     try:
         lib = C.CDLL(SO_PATH)
     except OSError as e:

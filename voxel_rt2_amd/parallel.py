@@ -1,0 +1,37 @@
+"""Row-tile sharding of the HDR frame across ranks and the gather to rank 0.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI on the MI355X node; "gloo"
+in the CPU tests).  Pixels are independent given the replicated scene and the per-pixel random
+streams, so a rank renders its contiguous rows (plus a small halo it renders redundantly) with no
+data-path communication; the only exchange is one gather of the finished tiles per presented frame:
+at 1080p each of 7 peers sends 135 x 1920 x 12 B = 3.1 MB straight to rank 0 over its own xGMI link.
+"""
+import numpy as np
+
+
+def split_rows(height, world_size):
+    """Contiguous row ranges, one per rank, covering [0, height)."""
+    edges = [(height * i) // world_size for i in range(world_size + 1)]
+    return [(edges[i], edges[i + 1]) for i in range(world_size)]
+
+
+def max_tile_rows(height, world_size):
+    return max(b - a for a, b in split_rows(height, world_size))
+
+
+def gather_frame(tile, height, width, rank, world_size, dst=0, out_list=None):
+    """Gather per-rank tiles (torch tensors [max_tile_rows, width, 3], rows past the tile unused) to
+    `dst` and return the assembled [height, width, 3] frame there (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+    if world_size == 1:
+        return tile[:height]
+    if rank == dst and out_list is None:
+        out_list = [torch.zeros_like(tile) for _ in range(world_size)]
+    dist.gather(tile, out_list if rank == dst else None, dst=dst)
+    if rank != dst:
+        return None
+    frame = torch.empty((height, width, 3), dtype=tile.dtype, device=tile.device)
+    for r, (a, b) in enumerate(split_rows(height, world_size)):
+        frame[a:b] = out_list[r][: b - a]
+    return frame
