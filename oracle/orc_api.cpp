@@ -90,8 +90,11 @@ int orc_accumulate(orc_ctx* c, int n) {
 }
 int orc_reset(orc_ctx* c) { c->r.reset_framebuffer(); return 0; }
 int orc_end_frame(orc_ctx* c) { c->r.copy_prev_matrices(); return 0; }
-int orc_fetch_hdr(orc_ctx* c, float* out) {
-    memcpy(out, c->r.color_buffer.data(), c->r.color_buffer.size() * sizeof(V3));
+int orc_fetch_hdr(orc_ctx* c, float* out) { /* rows outside [row_begin,row_end) are zero, like vrt_fetch_hdr */
+    const Renderer& r = c->r;
+    memset(out, 0, (size_t)r.W * r.H * sizeof(V3));
+    memcpy(out + (size_t)r.row_begin * r.W * 3, r.color_buffer.data() + (size_t)r.row_begin * r.W,
+           (size_t)(r.row_end - r.row_begin) * r.W * sizeof(V3));
     return 0;
 }
 int orc_fetch_ldr(orc_ctx* c, float* out) { c->r.render_to_image(out); return 0; }

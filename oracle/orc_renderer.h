@@ -417,7 +417,7 @@ struct Renderer {
             V3 sky_T = v3(1.0f);
             if (use_physical_atmosphere == 1) {
                 sky_T = atmos.sample_skybox_transmittance(first_light_sample_dir);
-                if (st) st->sky_lookups++;
+                if (st && use_restir) st->sky_lookups++; /* only feeds the reservoir: unobservable with ReSTIR off */
             }
             Sample light_sample;
             light_sample.F = first_vertex_NEE_diffuse + first_vertex_NEE_specular;

@@ -25,7 +25,8 @@ struct Emu {
     std::vector<float> mats, sky_scat, sky_trans;
     int buf0, buf1, own0, own1;
     size_t n;
-    std::vector<f3> color_d, color_s, color_d2, color_s2, gb_pos, hdr;
+    std::vector<f3> cbuf[2], color_s, color_d2, color_s2, gb_pos;
+    int cidx = 0;
     std::vector<uint32_t> gb_normal[2], gb_mat;
     std::vector<float> gb_depth[2], gb_refl, gb_refl_f;
     std::vector<f4> hist_d[2], hist_s[2];
@@ -78,8 +79,8 @@ Emu* emu_create(const vrt_config* cfg) {
     c->grid.assign(128 * 128 * 128, 0); c->l0.assign(32768, 0); c->l1.assign(512, 0); c->l2.assign(8, 0);
     c->mats.assign(128 * 14, 0.0f);
     f3 z = mk3(0.0f);
-    c->color_d.assign(n, z); c->color_s.assign(n, z); c->color_d2.assign(n, z); c->color_s2.assign(n, z);
-    c->gb_pos.assign(n, z); c->hdr.assign(n, z); c->gb_mat.assign(n, 0); c->gb_refl.assign(n, 0); c->gb_refl_f.assign(n, 0);
+    c->cbuf[0].assign(n, z); c->cbuf[1].assign(n, z); c->color_s.assign(n, z); c->color_d2.assign(n, z); c->color_s2.assign(n, z);
+    c->gb_pos.assign(n, z); c->gb_mat.assign(n, 0); c->gb_refl.assign(n, 0); c->gb_refl_f.assign(n, 0);
     for (int s = 0; s < 2; s++) {
         c->gb_normal[s].assign(n, 0); c->gb_depth[s].assign(n, 0);
         c->hist_d[s].assign(n, mk4(0, 0, 0, 0)); c->hist_s[s].assign(n, mk4(0, 0, 0, 0));
@@ -161,16 +162,18 @@ int emu_accumulate(Emu* c, int n_samples) {
         sc.sky.res = c->cfg.sky_res; sc.sky.fres = c->cfg.sky_res > 0 ? (float)(1.0 / (double)c->cfg.sky_res) : 0.0f;
         sc.counters = nullptr;
         PixelBuffers out;
-        out.color_d = c->color_d.data(); out.color_s = c->color_s.data();
+        f3* rt = c->cbuf[c->cidx].data();
+        f3* hdr = c->cbuf[c->cidx ^ 1].data();
+        out.color_d = rt; out.color_s = c->color_s.data();
         out.gb_normal = c->gb_normal[c->cur].data(); out.gb_depth = c->gb_depth[c->cur].data();
         out.gb_refl_depth = c->gb_refl.data(); out.gb_position = c->gb_pos.data(); out.gb_mat = c->gb_mat.data();
         out.reservoir = c->res[0].data();
-        const f3* cd = c->color_d.data();
+        const f3* cd = rt;
         const f3* cs = c->color_s.data();
         if (c->cfg.use_restir) {
             render_all<true>(c, fp, sc, out);
             GrisBuffers gb;
-            gb.color_d_in = c->color_d.data(); gb.color_s_in = c->color_s.data();
+            gb.color_d_in = rt; gb.color_s_in = c->color_s.data();
             gb.color_d_out = c->color_d2.data(); gb.color_s_out = c->color_s2.data();
             gb.gb_normal = out.gb_normal; gb.gb_depth = out.gb_depth; gb.gb_mat = out.gb_mat;
             gb.res_in = c->res[0].data(); gb.res_out = c->res[1].data();
@@ -191,11 +194,12 @@ int emu_accumulate(Emu* c, int n_samples) {
         tb.hist_d_in = c->hist_d[c->hist_in].data(); tb.hist_d_out = c->hist_d[c->hist_in ^ 1].data();
         tb.hist_s_in = c->hist_s[c->hist_in].data(); tb.hist_s_out = c->hist_s[c->hist_in ^ 1].data();
         tb.prev_normal = c->gb_normal[c->cur ^ 1].data(); tb.prev_depth = c->gb_depth[c->cur ^ 1].data();
-        tb.hdr = c->hdr.data();
+        tb.hdr = hdr;
         for (int v = c->own0; v < c->own1; v++)
             for (int u = 0; u < fp.W; u++) temporal_pixel(fp, tb, u, v);
         c->hist_in ^= 1;
         c->cur ^= 1;
+        c->cidx ^= 1;
         c->frame += 1;
     }
     return 0;
@@ -214,12 +218,12 @@ static void fetch_rows(Emu* c, const void* buf, size_t elem, void* out) {
     memcpy((char*)out + (size_t)c->own0 * W * elem, (const char*)buf + (size_t)(c->own0 - c->buf0) * W * elem,
            (size_t)(c->own1 - c->own0) * W * elem);
 }
-int emu_fetch_hdr(Emu* c, float* out) { fetch_rows(c, c->hdr.data(), 12, out); return 0; }
+int emu_fetch_hdr(Emu* c, float* out) { fetch_rows(c, c->cbuf[c->cidx].data(), 12, out); return 0; }
 int emu_fetch_ldr(Emu* c, float* out) {
     FrameParams fp = frame_params(c);
     std::vector<f4> ldr(c->n);
     for (int v = c->own0; v < c->own1; v++)
-        for (int u = 0; u < fp.W; u++) ldr[(v - fp.row0) * fp.W + u] = tonemap_pixel(fp, c->hdr.data(), u, v);
+        for (int u = 0; u < fp.W; u++) ldr[(v - fp.row0) * fp.W + u] = tonemap_pixel(fp, c->cbuf[c->cidx].data(), u, v);
     fetch_rows(c, ldr.data(), 16, out);
     return 0;
 }

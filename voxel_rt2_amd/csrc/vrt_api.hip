@@ -52,7 +52,9 @@ struct vrt_ctx {
     uint8_t* d_cloud_tex = nullptr;
     uint32_t cloud_pass = 0;
     // per-pixel
-    f3 *d_color_d = nullptr, *d_color_s = nullptr, *d_color_d2 = nullptr, *d_color_s2 = nullptr, *d_gb_pos = nullptr, *d_hdr = nullptr;
+    f3 *d_cbuf[2] = {nullptr, nullptr};  // color_buffer: [cidx] = HDR of the last pass = render target of the next (pathtracer.py:39)
+    int cidx = 0;
+    f3 *d_color_s = nullptr, *d_color_d2 = nullptr, *d_color_s2 = nullptr, *d_gb_pos = nullptr;
     uint32_t* d_gb_normal[2] = {nullptr, nullptr};
     float* d_gb_depth[2] = {nullptr, nullptr};
     uint32_t* d_gb_mat = nullptr;
@@ -197,8 +199,8 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
     ok = ok && dalloc(&c->d_mat, nvox) == hipSuccess && dalloc(&c->d_rgb, nvox * 3) == hipSuccess && dalloc(&c->d_grid, nvox) == hipSuccess;
     ok = ok && dalloc(&c->d_l0, 32768) == hipSuccess && dalloc(&c->d_l1, 512) == hipSuccess && dalloc(&c->d_l2, 8) == hipSuccess;
     ok = ok && dalloc(&c->d_mats, 128 * 14) == hipSuccess && dalloc(&c->d_counters, 1) == hipSuccess && dalloc(&c->d_work, 1) == hipSuccess;
-    ok = ok && dalloc(&c->d_color_d, n) == hipSuccess && dalloc(&c->d_color_s, n) == hipSuccess && dalloc(&c->d_gb_pos, n) == hipSuccess;
-    ok = ok && dalloc(&c->d_hdr, n) == hipSuccess && dalloc(&c->d_gb_mat, n) == hipSuccess && dalloc(&c->d_gb_refl, n) == hipSuccess;
+    ok = ok && dalloc(&c->d_cbuf[0], n) == hipSuccess && dalloc(&c->d_cbuf[1], n) == hipSuccess && dalloc(&c->d_color_s, n) == hipSuccess && dalloc(&c->d_gb_pos, n) == hipSuccess;
+    ok = ok && dalloc(&c->d_gb_mat, n) == hipSuccess && dalloc(&c->d_gb_refl, n) == hipSuccess;
     ok = ok && dalloc(&c->d_gb_refl_f, n) == hipSuccess && dalloc(&c->d_ldr, n) == hipSuccess;
     for (int s = 0; s < 2 && ok; s++) {
         ok = ok && dalloc(&c->d_gb_normal[s], n) == hipSuccess && dalloc(&c->d_gb_depth[s], n) == hipSuccess;
@@ -237,8 +239,8 @@ void vrt_destroy(vrt_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     resolve_events(c);
     void* ptrs[] = {c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_mats, c->d_counters, c->d_work, c->d_sky_scat,
-                    c->d_sky_trans, c->d_cloud_ambient, c->d_trans_lut, c->d_cloud_tex, c->d_color_d, c->d_color_s, c->d_color_d2,
-                    c->d_color_s2, c->d_gb_pos, c->d_hdr, c->d_gb_normal[0], c->d_gb_normal[1], c->d_gb_depth[0], c->d_gb_depth[1],
+                    c->d_sky_trans, c->d_cloud_ambient, c->d_trans_lut, c->d_cloud_tex, c->d_cbuf[0], c->d_cbuf[1], c->d_color_s, c->d_color_d2,
+                    c->d_color_s2, c->d_gb_pos, c->d_gb_normal[0], c->d_gb_normal[1], c->d_gb_depth[0], c->d_gb_depth[1],
                     c->d_gb_mat, c->d_gb_refl, c->d_gb_refl_f, c->d_hist_d[0], c->d_hist_d[1], c->d_hist_s[0], c->d_hist_s[1],
                     c->d_ldr, c->d_res[0], c->d_res[1]};
     for (void* p : ptrs)
@@ -361,7 +363,9 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         FrameParams fp = make_frame_params(c);
         SceneData sc = make_scene_data(c);
         PixelBuffers out;
-        out.color_d = c->d_color_d; out.color_s = c->d_color_s;
+        f3* rt = c->d_cbuf[c->cidx];       // render target: holds the previous HDR outside the render area
+        f3* hdr = c->d_cbuf[c->cidx ^ 1];
+        out.color_d = rt; out.color_s = c->d_color_s;
         out.gb_normal = c->d_gb_normal[c->cur]; out.gb_depth = c->d_gb_depth[c->cur];
         out.gb_refl_depth = c->d_gb_refl; out.gb_position = c->d_gb_pos; out.gb_mat = c->d_gb_mat;
         out.reservoir = c->d_res[0];
@@ -370,11 +374,11 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         HIP_TRY(hipEventRecord(a, c->stream));
         HIP_TRY(launch_render(c->stream, restir, instr, c->render_blocks, fp, sc, out, c->d_work));
         HIP_TRY(hipEventRecord(b, c->stream));
-        const f3* cd = c->d_color_d;
+        const f3* cd = rt;
         const f3* cs = c->d_color_s;
         if (restir) {
             GrisBuffers gb;
-            gb.color_d_in = c->d_color_d; gb.color_s_in = c->d_color_s; gb.color_d_out = c->d_color_d2; gb.color_s_out = c->d_color_s2;
+            gb.color_d_in = rt; gb.color_s_in = c->d_color_s; gb.color_d_out = c->d_color_d2; gb.color_s_out = c->d_color_s2;
             gb.gb_normal = out.gb_normal; gb.gb_depth = out.gb_depth; gb.gb_mat = out.gb_mat;
             gb.res_in = c->d_res[0]; gb.res_out = c->d_res[1];
             int g0 = c->own0 - 2 < c->buf0 ? c->buf0 : c->own0 - 2, g1 = c->own1 + 2 > c->buf1 ? c->buf1 : c->own1 + 2;
@@ -392,7 +396,7 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         tb.hist_d_in = c->d_hist_d[c->hist_in]; tb.hist_d_out = c->d_hist_d[c->hist_in ^ 1];
         tb.hist_s_in = c->d_hist_s[c->hist_in]; tb.hist_s_out = c->d_hist_s[c->hist_in ^ 1];
         tb.prev_normal = c->d_gb_normal[c->cur ^ 1]; tb.prev_depth = c->d_gb_depth[c->cur ^ 1];
-        tb.hdr = c->d_hdr;
+        tb.hdr = hdr;
         if (record(c, 1, &a, &b) != VRT_OK) return VRT_E_DEVICE;
         HIP_TRY(hipEventRecord(a, c->stream));
         HIP_TRY(launch_temporal(c->stream, fp, tb, c->own0, c->own1));
@@ -400,6 +404,7 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         // pathtracer.py:1298-1303 copy loop == pointer swaps
         c->hist_in ^= 1;
         c->cur ^= 1;
+        c->cidx ^= 1;
         c->frame += 1;
         c->stats.path_samples += (uint64_t)c->cfg.width * (uint64_t)(c->own1 - c->own0);
     }
@@ -442,13 +447,13 @@ static int fetch_rows(vrt_ctx* c, const void* dbuf, size_t elem, void* out) {
 }
 int vrt_fetch_hdr(vrt_ctx* c, float* out) {
     if (!c || !out) return fail(VRT_E_INVALID, "null argument");
-    return fetch_rows(c, c->d_hdr, sizeof(f3), out);
+    return fetch_rows(c, c->d_cbuf[c->cidx], sizeof(f3), out);
 }
 int vrt_fetch_hdr_device(vrt_ctx* c, void* device_ptr) {
     if (!c || !device_ptr) return fail(VRT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     const size_t W = c->cfg.width;
-    const char* src = (const char*)c->d_hdr + (size_t)(c->own0 - c->buf0) * W * sizeof(f3);
+    const char* src = (const char*)c->d_cbuf[c->cidx] + (size_t)(c->own0 - c->buf0) * W * sizeof(f3);
     HIP_TRY(hipMemcpyAsync(device_ptr, src, (size_t)(c->own1 - c->own0) * W * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return VRT_OK;
@@ -458,7 +463,7 @@ int vrt_fetch_ldr(vrt_ctx* c, float* out) {
     if (!c->have_cam) return fail(VRT_E_STATE, "vrt_set_camera has not been called");
     HIP_TRY(hipSetDevice(c->device));
     FrameParams fp = make_frame_params(c);
-    HIP_TRY(launch_tonemap(c->stream, fp, c->d_hdr, c->d_ldr, c->own0, c->own1));
+    HIP_TRY(launch_tonemap(c->stream, fp, c->d_cbuf[c->cidx], c->d_ldr, c->own0, c->own1));
     return fetch_rows(c, c->d_ldr, sizeof(f4), out);
 }
 int vrt_fetch_buffer(vrt_ctx* c, int which, void* out) {

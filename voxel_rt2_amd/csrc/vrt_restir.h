@@ -225,8 +225,12 @@ struct GrisBuffers {
 template <class PyrT>
 VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& P, const GrisBuffers& gb, int u, int v,
                         int pass_id, float max_radius, int max_taps, int pass_total, TraceStats& ts) {
-    if (outside_render_area(fp, (float)u, (float)v)) return;
     const int idx = (v - fp.row0) * fp.W + u;
+    if (outside_render_area(fp, (float)u, (float)v)) {  // untouched by the reference: carry the stale values across
+        gb.color_d_out[idx] = gb.color_d_in[idx];
+        gb.color_s_out[idx] = gb.color_s_in[idx];
+        return;
+    }
     dm_rng rng = dm_rng_init(fp.seed, fp.frame, (uint32_t)(v * fp.W + u), 1u);
     const f2 tc = pixel_texcoord(fp, (float)u, (float)v);
     (void)dm_rng_f32(&rng);  // start_index draw (:827), value unused

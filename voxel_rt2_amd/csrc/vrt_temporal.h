@@ -34,7 +34,7 @@ struct TemporalBuffers {
     f4* hist_s_out;
     const uint32_t* prev_normal;  // gbuff_prev_normals / gbuff_prev_depth
     const float* prev_depth;
-    f3* hdr;                      // color_buffer after accumulate()
+    f3* hdr;                      // color_buffer after accumulate(); becomes the next pass's render target
 };
 
 VRT_DEV f3 scrub(f3 c) {  // pathtracer.py:1069-1075
@@ -127,8 +127,15 @@ VRT_DEV void blend_history(const FrameParams& fp, float wsum, f4& h, f3 cur) {  
 
 // One pixel (u, v) of this shard's rows.
 VRT_DEV void temporal_pixel(const FrameParams& fp, const TemporalBuffers& tb, int u, int v) {
-    if (outside_render_area(fp, (float)u, (float)v)) return;
     const int idx = (v - fp.row0) * fp.W + u;
+    if (outside_render_area(fp, (float)u, (float)v)) {
+        // not rendered at this render_scale: the reference leaves color_buffer (= the last HDR value) untouched.
+        // The render target and the HDR target swap roles every pass, so carry the value across.
+        tb.hdr[idx] = tb.color_d[idx];
+        tb.hist_d_out[idx] = tb.hist_d_in[idx];
+        tb.hist_s_out[idx] = tb.hist_s_in[idx];
+        return;
+    }
     int rx, ry;
     render_res(fp, rx, ry);
 
