@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Throughput of the other BASELINE.json configs on one GPU (informational; bench.py is the judged line).
+Prints one JSON line per case: Mpath-samples/s, per-kernel ms, traversal counters per path-sample."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+from voxel_rt2_amd import host, scenes, materials, _lib
+from voxel_rt2_amd._session import NativeSession
+
+CASES = [
+    dict(name="config2_s1_1080p_d8", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=10),
+    dict(name="sunlit_1080p_d8", scene="sunlit", W=1920, H=1080, depth=8, spp=4, steps=10),
+    dict(name="config4_dense_4k_d8_1gpu", scene="dense", W=3840, H=2160, depth=8, spp=4, steps=4),
+    dict(name="config3_s6_sky_clouds_restir_1080p_d8", scene="s6", W=1920, H=1080, depth=8, spp=4, steps=5, restir=True, sky_res=3840),
+    dict(name="s6_sky_clouds_1080p_d8_norestir", scene="s6", W=1920, H=1080, depth=8, spp=4, steps=5, sky_res=3840),
+]
+
+
+def run(case):
+    lib = _lib.load()
+    mat, rgb, params = scenes.SCENES[case["scene"]](12345 if case["scene"] == "dense" else 0)
+    sky_res = case.get("sky_res", 0)
+    if not sky_res:
+        params = dict(params, use_physical_sky=0, use_clouds=0)
+    cfg = host.make_config(case["W"], case["H"], voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=case["depth"],
+                           seed=0, use_restir=case.get("restir", False), sky_res=sky_res)
+    s = NativeSession(lib, "vrt_", cfg)
+    s.upload_voxels(mat, rgb)
+    s.upload_materials(materials.load_table())
+    if sky_res:
+        s.upload_cloud_texture(np.load(os.path.join(ROOT, "voxel_rt2_amd", "data", "cloud_texture.npy")))
+    s.set_scene(host.make_scene_params(**params))
+    s.set_camera(host.default_camera(case["W"], case["H"], jitter_index=1))
+    s.prepare()
+    sky_s = 0.0
+    if sky_res:
+        s.sync()
+        t0 = time.perf_counter()
+        for _ in range(32):
+            s.sky_accumulate_clouds(32)
+        s.sync()
+        t1 = time.perf_counter()
+        for sl in range(32):
+            s.sky_compute_slice(sl, 32)
+        s.sync()
+        sky_s = time.perf_counter() - t0
+        print(json.dumps(dict(name=case["name"], sky_clouds_s=round(t1 - t0, 3), sky_slices_s=round(time.perf_counter() - t1, 3))), flush=True)
+    s.accumulate(case["spp"])
+    s.sync()
+    lib.vrt_reset_stats(C.c_void_p(s._ctx))
+    t0 = time.perf_counter()
+    for _ in range(case["steps"]):
+        s.accumulate(case["spp"])
+    s.sync()
+    dt = time.perf_counter() - t0
+    st = s.stats()
+    lib.vrt_set_instrumented(C.c_void_p(s._ctx), 1)
+    lib.vrt_reset_stats(C.c_void_p(s._ctx))
+    s.accumulate(1)
+    ist = s.stats()
+    n = ist["path_samples"]
+    hdr = s.fetch_hdr()
+    out = dict(name=case["name"], mpaths_per_s=round(case["W"] * case["H"] * case["spp"] * case["steps"] / dt / 1e6, 1),
+               render_ms=round(st["render_ms"] / max(st["render_launches"], 1), 3),
+               gris_ms=round(st["gris_ms"] / max(st["gris_launches"], 1), 3),
+               temporal_ms=round(st["temporal_ms"] / max(st["temporal_launches"], 1), 3),
+               rays_per_path=round(ist["rays"] / n, 2), iters_per_ray=round(ist["dda_iters"] / max(ist["rays"], 1), 2),
+               queries_per_path=round(ist["occupancy_queries"] / n, 1), hits_per_path=round(ist["closest_hits"] / n, 3),
+               sky_lookups_per_path=round(ist["sky_lookups"] / n, 3), sky_precompute_s=round(sky_s, 2),
+               hdr_mean=float(hdr.mean()), finite=bool(np.isfinite(hdr).all()))
+    print(json.dumps(out), flush=True)
+    s.close()
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for c in CASES:
+        if not only or any(o in c["name"] for o in only):
+            run(c)

@@ -5,7 +5,7 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libvrt_hip.so")
+SO_PATH = os.environ.get("VRT_LIB_PATH") or os.path.join(_HERE, "libvrt_hip.so")  # VRT_LIB_PATH: A/B builds of the same library
 _lib = None
 
 

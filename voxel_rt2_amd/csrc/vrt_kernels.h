@@ -12,6 +12,9 @@
 #include "vrt_temporal.h"
 
 #define VRT_RENDER_THREADS 256
+#ifndef VRT_RENDER_MIN_WAVES
+#define VRT_RENDER_MIN_WAVES 2   // waves per SIMD the register allocator must leave room for (tuned on MI355X)
+#endif
 
 namespace vrt {
 

@@ -16,6 +16,7 @@
 // in L2 / Infinity Cache.  Every wave reaches the exit: the loop ends when the counter is exhausted
 // and no lane holds a path.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "vrt_kernels.h"
 
 namespace vrt {
@@ -83,13 +84,14 @@ __device__ __forceinline__ void flush_stats(const TraceStats& ts, Counters* c) {
 }
 
 template <bool RESTIR, bool INSTR>
-__global__ __launch_bounds__(VRT_RENDER_THREADS) void k_render(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter) {
+__global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_render(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, unsigned chunk) {
     __shared__ unsigned long long s_l1[512];
     __shared__ unsigned long long s_l2[8];
     __shared__ float s_mats[128 * 14];
     for (int i = threadIdx.x; i < 512; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
     if (threadIdx.x < 8) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
     for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *next_counter = 0u;  // the next launch's counter (idle during this launch)
     __syncthreads();
     LdsPyramid P;
     P.l0 = sc.pyr.l0; P.l1 = s_l1; P.l2 = s_l2;
@@ -106,19 +108,29 @@ __global__ __launch_bounds__(VRT_RENDER_THREADS) void k_render(FrameParams fp, S
     int local_idx = 0;
     TraceStats ts;
     stats_zero(ts);
-    bool exhausted = false;  // wave-uniform
+    bool exhausted = false;               // wave-uniform
+    unsigned chunk_next = 0u, chunk_end = 0u;  // wave-uniform: pixels [chunk_next, chunk_end) are reserved for this wave
 
     for (;;) {
         const bool need = p.depth < 0;
         const unsigned long long mask = __ballot(need);
         if (mask != 0ULL && !exhausted) {
+            // One returning atomic on a single word saturates near 88 dequeues/us chip-wide (MI355X_MICROARCH.md,
+            // row `dequeue`): a wave therefore reserves `chunk` pixels at a time and hands them to its lanes itself.
+            if (chunk_next == chunk_end) {
+                unsigned base = 0u;
+                if (lane == 0) base = atomicAdd(work_counter, chunk);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                chunk_next = base < total ? base : total;
+                chunk_end = (base + chunk < total) ? base + chunk : total;
+                if (base >= total) { exhausted = true; chunk_end = chunk_next; }
+            }
+            const unsigned avail = chunk_end - chunk_next;
             const unsigned n = (unsigned)__popcll(mask);
-            unsigned base = 0u;
-            if (lane == (int)__ffsll((long long)mask) - 1) base = atomicAdd(work_counter, n);
-            base = (unsigned)__shfl((int)base, (int)__ffsll((long long)mask) - 1, 64);
-            if (base + n >= total) exhausted = true;
-            const unsigned my = base + (unsigned)__popcll(mask & ((1ULL << lane) - 1ULL));
-            if (need && my < total) {
+            const unsigned rank = (unsigned)__popcll(mask & ((1ULL << lane) - 1ULL));
+            const unsigned my = chunk_next + rank;
+            chunk_next += (n < avail) ? n : avail;
+            if (need && rank < avail) {
                 const unsigned tile = my >> 6, in = my & 63u;
                 const int u = (int)(tile % (unsigned)tiles_x) * 8 + (int)(in & 7u);
                 const int v = fp.row0 + (int)(tile / (unsigned)tiles_x) * 8 + (int)(in >> 3);
@@ -224,16 +236,22 @@ hipError_t query_render_residency(bool restir, bool instr, int* blocks_per_cu) {
 }
 
 hipError_t launch_render(hipStream_t st, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
-                         const PixelBuffers& out, unsigned* work_counter) {
-    hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(unsigned), st);
-    if (e != hipSuccess) return e;
+                         const PixelBuffers& out, unsigned* work_counters) {
+    // two counters alternate between launches: this launch counts on one and zeroes the other for the next launch
+    unsigned* work_counter = work_counters + (fp.frame & 1u);
+    unsigned* next_counter = work_counters + ((fp.frame + 1u) & 1u);
     dim3 g(n_blocks), b(VRT_RENDER_THREADS);
+    // pixels a wave reserves per atomic: whole 8x8 tiles.  One tile keeps the tail short (measured: 192-pixel chunks
+    // cost 13 % at 1080p on the sparse scene) and still cuts the atomic rate ~3x against per-refill atomics, which
+    // is what the dense 4K frame needed (67 -> 22 dequeues/us, 5.9 -> 4.8 ms).  VRT_CHUNK overrides for experiments.
+    unsigned chunk = 64u;
+    if (const char* e = getenv("VRT_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 4096) chunk = (unsigned)(v / 64 * 64); }
     if (restir) {
-        if (instr) hipLaunchKernelGGL((k_render<true, true>), g, b, 0, st, fp, sc, out, work_counter);
-        else hipLaunchKernelGGL((k_render<true, false>), g, b, 0, st, fp, sc, out, work_counter);
+        if (instr) hipLaunchKernelGGL((k_render<true, true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk);
+        else hipLaunchKernelGGL((k_render<true, false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk);
     } else {
-        if (instr) hipLaunchKernelGGL((k_render<false, true>), g, b, 0, st, fp, sc, out, work_counter);
-        else hipLaunchKernelGGL((k_render<false, false>), g, b, 0, st, fp, sc, out, work_counter);
+        if (instr) hipLaunchKernelGGL((k_render<false, true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk);
+        else hipLaunchKernelGGL((k_render<false, false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk);
     }
     VRT_LAUNCH_CHECK();
     return hipSuccess;

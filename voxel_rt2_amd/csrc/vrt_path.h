@@ -213,23 +213,38 @@ VRT_DEV bool path_segment(const FrameParams& fp, const SceneData& sc, const PyrT
         Surf s;
         surf_init(s, m, h.normal, -p.d);
 
-        // next-event estimation toward the cone sun (pathtracer.py:435-476)
+        // Sun sample (pathtracer.py:435-476) and next direction (478-497).  The random draws keep the reference's
+        // order -- two for the cone, then the BSDF sampler's -- but the shadow ray, which draws nothing, is traced
+        // AFTER the BSDF sample and only when its answer can reach the image:
+        //   (a) the sun emits (light_color * light_weight != 0): the light sample contributes; or
+        //   (b) the sampled bounce direction lies inside the sun cone, where NEE_visible enters its MIS weight (:490-491).
+        // With a black sun (scene.py:127's default, e.g. example1.py) the light-sample terms are exact zeros
+        // (firefly() maps a NaN product to 0), so the ray and the BSDF evaluation behind it are skipped.
+        f3 lx, ly;
+        ortho_basis(fp.light_dir, lx, ly);
+        const f3 ldir = cone_dir(fp.light_cos_max, fp.light_dir, lx, ly, p.rng);
+        const float ndl = dot3(ldir, h.normal);
+        const bool light_on = (fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f;
+        if constexpr (RESTIR) {
+            if (depth == 0) { p.rs.first_light_bsdf_pdf = pdf_all(s, ldir); p.rs.first_light_dir = ldir; }
+        }
+        const bool final_segment = (depth > 0) && (depth + 1 >= fp.max_depth) && !RESTIR;  // its bounce is never traced
+        f3 brdf = mk3(0.0f), next_d = p.d;
+        float pdf = 1.0f, bounce_light_pdf = 0.0f;
+        int lobe = 0;
+        if (!final_segment) {
+            next_d = sample_bsdf(s, p.rng, brdf, pdf, lobe);
+            bounce_light_pdf = cone_pdf(fp.light_cos_max, dot3(fp.light_dir, next_d));
+        }
         float nee_visible = 0.0f;
-        {
-            f3 lx, ly;
-            ortho_basis(fp.light_dir, lx, ly);
-            const f3 ldir = cone_dir(fp.light_cos_max, fp.light_dir, lx, ly, p.rng);
-            const float ndl = dot3(ldir, h.normal);
-            const float light_bsdf_pdf = pdf_all(s, ldir);
-            if constexpr (RESTIR) {
-                if (depth == 0) { p.rs.first_light_bsdf_pdf = light_bsdf_pdf; p.rs.first_light_dir = ldir; }
-            }
-            if (ndl > 0.0f) {
-                Hit sh;
-                next_hit<true>(fp, sc, P, p.pos, ldir, sh, ts);
-                if (sh.closest >= DM_INF) {
-                    nee_visible = 1.0f;
-                    if constexpr (RESTIR) { if (depth == 1) p.rs.rc_nee_dir = ldir; }
+        if (ndl > 0.0f && (RESTIR || light_on || (depth > 0 && bounce_light_pdf > 0.0f))) {
+            Hit sh;
+            next_hit<true>(fp, sc, P, p.pos, ldir, sh, ts);
+            if (sh.closest >= DM_INF) {
+                nee_visible = 1.0f;
+                if constexpr (RESTIR) { if (depth == 1) p.rs.rc_nee_dir = ldir; }
+                if (RESTIR || light_on) {
+                    const float light_bsdf_pdf = pdf_all(s, ldir);
                     float w = 1.0f;
                     if (depth > 0) w = power_heuristic(cone_pdf(fp.light_cos_max, 1.0f), light_bsdf_pdf);
                     f3 bd, bs;
@@ -254,26 +269,23 @@ VRT_DEV bool path_segment(const FrameParams& fp, const SceneData& sc, const PyrT
                 }
             }
         }
+        p.depth = depth + 1;
+        if (final_segment) return true;
 
-        // next direction (pathtracer.py:478-497)
-        f3 brdf;
-        float pdf;
-        int lobe;
-        p.d = sample_bsdf(s, p.rng, brdf, pdf, lobe);
-        f3 bw = brdf * dm_saturate(dot3(p.d, h.normal));
+        p.d = next_d;
+        f3 bw = brdf * dm_saturate(dot3(next_d, h.normal));
         if (depth == 0) {
             p.first_invpdf = 1.0f / pdf;
             p.first_lobe = lobe;
         } else {
             bw = bw / pdf;
-            bw = bw * power_heuristic(pdf, nee_visible * cone_pdf(fp.light_cos_max, dot3(fp.light_dir, p.d)));
+            bw = bw * power_heuristic(pdf, nee_visible * bounce_light_pdf);
             if constexpr (RESTIR) {
                 if (depth == 1) p.rs.rc_lobe = lobe;
                 if (depth >= 2) p.rs.thr_after_rc = p.rs.thr_after_rc * bw;
             }
         }
         p.thr = p.thr * bw;
-        p.depth = depth + 1;
         return p.depth >= fp.max_depth;
     }
 

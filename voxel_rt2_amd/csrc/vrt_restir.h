@@ -306,11 +306,16 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     // visibility of the chosen sample's reconnection (:959-967)
     bool force_canonical = false;
     const bool out_escape = near_zero3(outr.z.rc_normal);
-    const f3 to_rc = out_escape ? outr.z.rc_pos : norm3(outr.z.rc_pos - cx1);
-    Hit sh;
-    next_hit<true>(fp, sc, P, cx1 + cn1 * 0.003f * cdist, to_rc, sh, ts);
-    const float actual = out_escape ? DM_INF : len3(cx1 - outr.z.rc_pos);
-    if (sh.closest < DM_INF && dm_abs(sh.closest - actual) > 0.1f * actual) { outr.weight = 0.0f; force_canonical = true; }
+    // For an escape vertex the reference compares against actual_dist = inf: |dist - inf| > 0.1 * inf is never true,
+    // so that ray's result cannot be observed -- and an EMPTY output reservoir (rc_pos = 0) would make it a
+    // zero-direction ray that spins the DDA for all 512 iterations.  Only the reconnection case is traced.
+    if (!out_escape) {
+        const f3 to_rc = norm3(outr.z.rc_pos - cx1);
+        Hit sh;
+        next_hit<true>(fp, sc, P, cx1 + cn1 * 0.003f * cdist, to_rc, sh, ts);
+        const float actual = len3(cx1 - outr.z.rc_pos);
+        if (sh.closest < DM_INF && dm_abs(sh.closest - actual) > 0.1f * actual) { outr.weight = 0.0f; force_canonical = true; }
+    }
 
     if (reservoir_add(outr, center.z, center.M, center.weight * lum(center.z.F) * canonical_mis, rng, force_canonical)) {
         chosen_d = gb.color_d_in[idx];
