@@ -11,6 +11,7 @@ default 0), VRT_SEED, VRT_SKY_RES (default 3840).
 import ctypes as C
 import math
 import os
+import struct
 import numpy as np
 
 from . import _abi, _lib, camera as cam_mod, host, materials
@@ -37,7 +38,56 @@ class _AtmosProxy:
         self.use_clouds = _Field(0, on_change)
 
 
-class Renderer:
+_F32 = struct.Struct("f")
+
+
+def _f32(x):
+    """x rounded to binary32 (the reference's voxel colours are f32 vectors)."""
+    return _F32.unpack(_F32.pack(x))[0]
+
+
+class VoxelStore:
+    """Renderer.set_voxel / get_voxel and their storage (pathtracer.py:1325-1334, voxel_world.py:7-18):
+    int8 material + uint8 rgb per voxel, index (x+64, y+64, z+64).  Kept on the host because the example
+    kernels author the scene on the host; bytearray-backed so a per-voxel call costs ~1 us."""
+
+    def _init_voxels(self):
+        self._mat = bytearray(128 * 128 * 128)
+        self._rgb = bytearray(128 * 128 * 128 * 3)
+        self.voxel_material = np.frombuffer(self._mat, dtype=np.int8).reshape(128, 128, 128)
+        self.voxel_color = np.frombuffer(self._rgb, dtype=np.uint8).reshape(128, 128, 128, 3)
+        self._voxels_dirty = True
+
+    def set_voxel(self, idx, mat, color):
+        x, y, z = int(idx[0]) + 64, int(idx[1]) + 64, int(idx[2]) + 64
+        if not (0 <= x < 128 and 0 <= y < 128 and 0 <= z < 128):
+            return  # the reference writes out of bounds here (undefined behaviour)
+        i = (x * 128 + y) * 128 + z
+        self._mat[i] = int(mat) & 0xFF  # ti.cast(mat, ti.i8)
+        rgb = self._rgb
+        j = 3 * i
+        for k in (0, 1, 2):  # math_utils.py:86-92: u8(clamp(c, 0, 1) * 255), evaluated in f32
+            c = _f32(color[k])
+            c = 0.0 if c < 0.0 else (1.0 if c > 1.0 else c)
+            rgb[j + k] = int(_f32(c * 255.0))
+        self._voxels_dirty = True
+
+    def get_voxel(self, ijk):
+        x, y, z = int(ijk[0]) + 64, int(ijk[1]) + 64, int(ijk[2]) + 64
+        if not (0 <= x < 128 and 0 <= y < 128 and 0 <= z < 128):
+            return 0, (0.0, 0.0, 0.0)
+        i = (x * 128 + y) * 128 + z
+        m = self._mat[i]
+        j = 3 * i
+        return (m - 256 if m > 127 else m), (_f32(self._rgb[j] / 255.0), _f32(self._rgb[j + 1] / 255.0), _f32(self._rgb[j + 2] / 255.0))
+
+    def set_voxel_arrays(self, mat, rgb):
+        self.voxel_material[...] = mat
+        self.voxel_color[...] = rgb
+        self._voxels_dirty = True
+
+
+class Renderer(VoxelStore):
     def __init__(self, dx, image_res, up, voxel_edges, exposure=3, *, max_depth=None, use_restir=None, seed=None, sky_res=None,
                  device=0, rows=None):
         self.image_res = tuple(int(x) for x in image_res)
@@ -54,9 +104,7 @@ class Renderer:
         self._s = NativeSession(_lib.load(), "vrt_", cfg)
 
         # voxel storage the user kernels write through set_voxel (voxel_world.py:7-18)
-        self.voxel_material = np.zeros((128, 128, 128), dtype=np.int8)
-        self.voxel_color = np.zeros((128, 128, 128, 3), dtype=np.uint8)
-        self._voxels_dirty = True
+        self._init_voxels()
 
         dirty = self._mark_scene_dirty
         self.floor_height = _Field(0.0, dirty)       # pathtracer.py:91-93
@@ -124,29 +172,6 @@ class Renderer:
     def copy_prev_matrices(self):
         self._push()
         self._s.end_frame()
-
-    # -- voxels (pathtracer.py:1325-1334; host-side because the scene is authored on the host) ----
-    def set_voxel(self, idx, mat, color):
-        x, y, z = int(idx[0]) + 64, int(idx[1]) + 64, int(idx[2]) + 64
-        if not (0 <= x < 128 and 0 <= y < 128 and 0 <= z < 128):
-            return  # the reference writes out of bounds here (undefined behaviour)
-        m = int(mat)
-        self.voxel_material[x, y, z] = ((m + 128) % 256) - 128  # ti.cast(mat, ti.i8)
-        c = np.clip(np.asarray([color[0], color[1], color[2]], dtype=np.float32), np.float32(0.0), np.float32(1.0))
-        self.voxel_color[x, y, z] = (c * np.float32(255.0)).astype(np.uint8)
-        self._voxels_dirty = True
-
-    def get_voxel(self, ijk):
-        x, y, z = int(ijk[0]) + 64, int(ijk[1]) + 64, int(ijk[2]) + 64
-        if not (0 <= x < 128 and 0 <= y < 128 and 0 <= z < 128):
-            return 0, (0.0, 0.0, 0.0)
-        c = self.voxel_color[x, y, z].astype(np.float32) / np.float32(255.0)
-        return int(self.voxel_material[x, y, z]), (float(c[0]), float(c[1]), float(c[2]))
-
-    def set_voxel_arrays(self, mat, rgb):
-        self.voxel_material[...] = mat
-        self.voxel_color[...] = rgb
-        self._voxels_dirty = True
 
     # -- state push -------------------------------------------------------------------------
     def _push(self):
