@@ -42,7 +42,6 @@ static FrameParams frame_params(const Emu* c) {
     memset(&fp, 0, sizeof(fp));
     memcpy(fp.view.m, c->cam.view, 64); memcpy(fp.proj.m, c->cam.proj, 64);
     memcpy(fp.view_inv.m, c->cam.view_inv, 64); memcpy(fp.proj_inv.m, c->cam.proj_inv, 64);
-    fp.prev_view = c->prev_view; fp.prev_proj = c->prev_proj;
     fp.camera_pos = mk3(c->cam.pos[0], c->cam.pos[1], c->cam.pos[2]);
     const int W = c->cfg.width, H = c->cfg.height;
     fp.inv_res = mk2((float)(1.0 / (double)W), (float)(1.0 / (double)H));
@@ -143,7 +142,7 @@ static void render_all(Emu* c, const FrameParams& fp, const SceneData& sc, const
         for (int u = 0; u < fp.W; u++) {
             if (outside_render_area(fp, (float)u, (float)v)) continue;
             Path<RESTIR> p;
-            path_begin(fp, p, u, v);
+            path_begin(fp, p, u, v, 0);
             int idx = (v - fp.row0) * fp.W + u;
             while (!path_segment<RESTIR>(fp, sc, P, out, idx, p, c->ts)) {}
             path_finish<RESTIR>(fp, sc, out, idx, p, c->ts);
@@ -168,6 +167,7 @@ int emu_accumulate(Emu* c, int n_samples) {
         out.gb_normal = c->gb_normal[c->cur].data(); out.gb_depth = c->gb_depth[c->cur].data();
         out.gb_refl_depth = c->gb_refl.data(); out.gb_position = c->gb_pos.data(); out.gb_mat = c->gb_mat.data();
         out.reservoir = c->res[0].data();
+        out.sample_stride = 0;
         const f3* cd = rt;
         const f3* cs = c->color_s.data();
         if (c->cfg.use_restir) {
@@ -195,8 +195,10 @@ int emu_accumulate(Emu* c, int n_samples) {
         tb.hist_s_in = c->hist_s[c->hist_in].data(); tb.hist_s_out = c->hist_s[c->hist_in ^ 1].data();
         tb.prev_normal = c->gb_normal[c->cur ^ 1].data(); tb.prev_depth = c->gb_depth[c->cur ^ 1].data();
         tb.hdr = hdr;
+        tb.sample_stride = 0;
+        tb.prev_view = c->prev_view; tb.prev_proj = c->prev_proj;
         for (int v = c->own0; v < c->own1; v++)
-            for (int u = 0; u < fp.W; u++) temporal_pixel(fp, tb, u, v);
+            for (int u = 0; u < fp.W; u++) temporal_pixel(fp, tb, u, v, 1);
         c->hist_in ^= 1;
         c->cur ^= 1;
         c->cidx ^= 1;

@@ -280,3 +280,27 @@ def test_scene_api_end_to_end(tmp_path, monkeypatch):
         o.accumulate(1)
         o.end_frame()
     assert np.array_equal(sc.hdr.view(np.uint32), o.fetch_hdr().view(np.uint32))
+
+
+def test_fused_samples_equal_separate_launches(monkeypatch):
+    """vrt_accumulate(n) fuses up to 4 samples into one render + one temporal launch; the result must be the same
+    bits as n single-sample calls (and as the oracle, which has no such notion)."""
+    mat, rgb, params = scenes.scene_sunlit(0)
+    cfg = host.make_config(200, 120, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=6, seed=13)
+    fused, single, o = gpu_session(cfg), gpu_session(cfg), orc.Oracle(cfg)
+    for s in (fused, single, o):
+        orc.setup(s, mat, rgb, params)
+    fused.accumulate(7)           # 4 + 3
+    for _ in range(7):
+        single.accumulate(1)
+    o.accumulate(7)
+    a, b, c = fused.fetch_hdr(), single.fetch_hdr(), o.fetch_hdr()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+    for which in (_abi.BUF_GBUF_DEPTH, _abi.BUF_GBUF_NORMAL, _abi.BUF_GBUF_REFL_DEPTH, _abi.BUF_HISTORY_DIFFUSE, _abi.BUF_HISTORY_SPECULAR):
+        assert np.array_equal(fused.fetch_buffer(which).view(np.uint8), o.fetch_buffer(which).view(np.uint8)), which
+    monkeypatch.setenv("VRT_FUSE", "1")
+    nofuse = gpu_session(cfg)
+    orc.setup(nofuse, mat, rgb, params)
+    nofuse.accumulate(7)
+    assert np.array_equal(nofuse.fetch_hdr().view(np.uint32), a.view(np.uint32))

@@ -7,11 +7,14 @@
 // redundantly instead of exchanging them: per-pixel random streams make them bit-identical).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 #include "../../include/vrt_api.h"
 #include "vrt_kernels.h"
+
+#define VRT_MAX_FUSED 4   // samples of one vrt_accumulate(n) call rendered by a single launch
 
 using namespace vrt;
 
@@ -55,6 +58,9 @@ struct vrt_ctx {
     f3 *d_cbuf[2] = {nullptr, nullptr};  // color_buffer: [cidx] = HDR of the last pass = render target of the next (pathtracer.py:39)
     int cidx = 0;
     f3 *d_color_s = nullptr, *d_color_d2 = nullptr, *d_color_s2 = nullptr, *d_gb_pos = nullptr;
+    f3* d_multi_d = nullptr;        // diffuse colour planes of the samples fused into one launch (allocated on first use)
+    f3* d_spec_planes = nullptr;    // VRT_MAX_FUSED specular planes; d_color_s = the last one
+    float* d_refl_planes = nullptr; // likewise for the raw reflection depth; d_gb_refl = the last one
     uint32_t* d_gb_normal[2] = {nullptr, nullptr};
     float* d_gb_depth[2] = {nullptr, nullptr};
     uint32_t* d_gb_mat = nullptr;
@@ -66,6 +72,7 @@ struct vrt_ctx {
     int hist_in = 0;  // history ping-pong
     mat4 prev_view{}, prev_proj{};
     uint32_t frame = 0;
+    unsigned launch_seq = 0;  // render launches so far (selects which of the two work counters a launch uses)
     // stats
     std::vector<EventPair> pending;
     vrt_stats stats{};
@@ -99,8 +106,6 @@ static FrameParams make_frame_params(const vrt_ctx* c) {
     memcpy(fp.proj.m, c->cam.proj, 64);
     memcpy(fp.view_inv.m, c->cam.view_inv, 64);
     memcpy(fp.proj_inv.m, c->cam.proj_inv, 64);
-    fp.prev_view = c->prev_view;
-    fp.prev_proj = c->prev_proj;
     fp.camera_pos = mk3(c->cam.pos[0], c->cam.pos[1], c->cam.pos[2]);
     const int W = c->cfg.width, H = c->cfg.height;
     fp.inv_res = mk2((float)(1.0 / (double)W), (float)(1.0 / (double)H));
@@ -199,8 +204,9 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
     ok = ok && dalloc(&c->d_mat, nvox) == hipSuccess && dalloc(&c->d_rgb, nvox * 3) == hipSuccess && dalloc(&c->d_grid, nvox) == hipSuccess;
     ok = ok && dalloc(&c->d_l0, 32768) == hipSuccess && dalloc(&c->d_l1, 512) == hipSuccess && dalloc(&c->d_l2, 8) == hipSuccess;
     ok = ok && dalloc(&c->d_mats, 128 * 14) == hipSuccess && dalloc(&c->d_counters, 1) == hipSuccess && dalloc(&c->d_work, 2) == hipSuccess;
-    ok = ok && dalloc(&c->d_cbuf[0], n) == hipSuccess && dalloc(&c->d_cbuf[1], n) == hipSuccess && dalloc(&c->d_color_s, n) == hipSuccess && dalloc(&c->d_gb_pos, n) == hipSuccess;
-    ok = ok && dalloc(&c->d_gb_mat, n) == hipSuccess && dalloc(&c->d_gb_refl, n) == hipSuccess;
+    ok = ok && dalloc(&c->d_cbuf[0], n) == hipSuccess && dalloc(&c->d_cbuf[1], n) == hipSuccess && dalloc(&c->d_spec_planes, n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->d_gb_pos, n) == hipSuccess;
+    ok = ok && dalloc(&c->d_gb_mat, n) == hipSuccess && dalloc(&c->d_refl_planes, n * VRT_MAX_FUSED) == hipSuccess;
+    if (ok) { c->d_color_s = c->d_spec_planes + (size_t)(VRT_MAX_FUSED - 1) * n; c->d_gb_refl = c->d_refl_planes + (size_t)(VRT_MAX_FUSED - 1) * n; }
     ok = ok && dalloc(&c->d_gb_refl_f, n) == hipSuccess && dalloc(&c->d_ldr, n) == hipSuccess;
     for (int s = 0; s < 2 && ok; s++) {
         ok = ok && dalloc(&c->d_gb_normal[s], n) == hipSuccess && dalloc(&c->d_gb_depth[s], n) == hipSuccess;
@@ -239,10 +245,10 @@ void vrt_destroy(vrt_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     resolve_events(c);
     void* ptrs[] = {c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_mats, c->d_counters, c->d_work, c->d_sky_scat,
-                    c->d_sky_trans, c->d_cloud_ambient, c->d_trans_lut, c->d_cloud_tex, c->d_cbuf[0], c->d_cbuf[1], c->d_color_s, c->d_color_d2,
+                    c->d_sky_trans, c->d_cloud_ambient, c->d_trans_lut, c->d_cloud_tex, c->d_cbuf[0], c->d_cbuf[1], c->d_spec_planes, c->d_color_d2,
                     c->d_color_s2, c->d_gb_pos, c->d_gb_normal[0], c->d_gb_normal[1], c->d_gb_depth[0], c->d_gb_depth[1],
-                    c->d_gb_mat, c->d_gb_refl, c->d_gb_refl_f, c->d_hist_d[0], c->d_hist_d[1], c->d_hist_s[0], c->d_hist_s[1],
-                    c->d_ldr, c->d_res[0], c->d_res[1]};
+                    c->d_gb_mat, c->d_refl_planes, c->d_gb_refl_f, c->d_hist_d[0], c->d_hist_d[1], c->d_hist_s[0], c->d_hist_s[1],
+                    c->d_ldr, c->d_res[0], c->d_res[1], c->d_multi_d};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -358,24 +364,41 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         if (per_cu > 8) per_cu = 8;
         c->render_blocks = per_cu * c->n_cu;
     }
-    for (int s = 0; s < n_samples; s++) {
+    // The samples of one call share camera, jitter and scene; with a still camera at full render scale and ReSTIR
+    // off they only differ in their random streams, so up to VRT_MAX_FUSED of them go through ONE k_render launch
+    // (work items = pixels x samples: 4x the parallelism per launch, one tail instead of four) into consecutive
+    // colour planes, and ONE k_temporal launch advances the running means sample by sample in registers.
+    int max_fused = VRT_MAX_FUSED;
+    if (const char* e = getenv("VRT_FUSE")) { int v = atoi(e); if (v >= 1 && v <= VRT_MAX_FUSED) max_fused = v; }
+    const bool can_fuse = !restir && c->cam.camera_is_moving == 0 && c->cam.render_scale == 1.0f;
+    for (int done = 0; done < n_samples;) {
+        int g = (can_fuse && n_samples - done > 1) ? (n_samples - done < max_fused ? n_samples - done : max_fused) : 1;
+        if (g > 1 && !c->d_multi_d) {
+            if (dalloc(&c->d_multi_d, c->npix * VRT_MAX_FUSED) != hipSuccess) { (void)hipGetLastError(); c->d_multi_d = nullptr; g = 1; }  // no memory: one launch per sample
+        }
         if (c->pending.size() > 192) resolve_events(c);
         FrameParams fp = make_frame_params(c);
         SceneData sc = make_scene_data(c);
         PixelBuffers out;
         f3* rt = c->d_cbuf[c->cidx];       // render target: holds the previous HDR outside the render area
         f3* hdr = c->d_cbuf[c->cidx ^ 1];
-        out.color_d = rt; out.color_s = c->d_color_s;
+        // specular colour and raw reflection depth: VRT_MAX_FUSED planes each, the LAST plane being the buffer the
+        // reference knows (color_buffer_specular, gbuff_depth_reflection); a fused launch ends on it, so whatever
+        // later reads stale pixels (moving camera at half render scale) finds the last sample there, as in the reference
+        out.color_d = g > 1 ? c->d_multi_d : rt;
+        out.color_s = c->d_color_s - (size_t)(g - 1) * c->npix;
+        out.gb_refl_depth = c->d_gb_refl - (size_t)(g - 1) * c->npix;
+        out.sample_stride = g > 1 ? (int)c->npix : 0;
         out.gb_normal = c->d_gb_normal[c->cur]; out.gb_depth = c->d_gb_depth[c->cur];
-        out.gb_refl_depth = c->d_gb_refl; out.gb_position = c->d_gb_pos; out.gb_mat = c->d_gb_mat;
+        out.gb_position = c->d_gb_pos; out.gb_mat = c->d_gb_mat;
         out.reservoir = c->d_res[0];
         hipEvent_t a, b;
         if (record(c, 0, &a, &b) != VRT_OK) return VRT_E_DEVICE;
         HIP_TRY(hipEventRecord(a, c->stream));
-        HIP_TRY(launch_render(c->stream, restir, instr, c->render_blocks, fp, sc, out, c->d_work));
+        HIP_TRY(launch_render(c->stream, restir, instr, c->render_blocks, fp, sc, out, c->d_work, c->launch_seq++, g));
         HIP_TRY(hipEventRecord(b, c->stream));
-        const f3* cd = rt;
-        const f3* cs = c->d_color_s;
+        const f3* cd = out.color_d;
+        const f3* cs = out.color_s;
         if (restir) {
             GrisBuffers gb;
             gb.color_d_in = rt; gb.color_s_in = c->d_color_s; gb.color_d_out = c->d_color_d2; gb.color_s_out = c->d_color_s2;
@@ -392,21 +415,24 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         TemporalBuffers tb;
         tb.color_d = cd; tb.color_s = cs;
         tb.gb_normal = out.gb_normal; tb.gb_depth = out.gb_depth; tb.gb_mat = out.gb_mat;
-        tb.gb_refl_raw = c->d_gb_refl; tb.gb_refl_filtered = c->d_gb_refl_f;
+        tb.gb_refl_raw = out.gb_refl_depth; tb.gb_refl_filtered = c->d_gb_refl_f;
         tb.hist_d_in = c->d_hist_d[c->hist_in]; tb.hist_d_out = c->d_hist_d[c->hist_in ^ 1];
         tb.hist_s_in = c->d_hist_s[c->hist_in]; tb.hist_s_out = c->d_hist_s[c->hist_in ^ 1];
         tb.prev_normal = c->d_gb_normal[c->cur ^ 1]; tb.prev_depth = c->d_gb_depth[c->cur ^ 1];
         tb.hdr = hdr;
+        tb.sample_stride = out.sample_stride;
+        tb.prev_view = c->prev_view; tb.prev_proj = c->prev_proj;
         if (record(c, 1, &a, &b) != VRT_OK) return VRT_E_DEVICE;
         HIP_TRY(hipEventRecord(a, c->stream));
-        HIP_TRY(launch_temporal(c->stream, fp, tb, c->own0, c->own1));
+        HIP_TRY(launch_temporal(c->stream, fp, tb, c->own0, c->own1, g));
         HIP_TRY(hipEventRecord(b, c->stream));
         // pathtracer.py:1298-1303 copy loop == pointer swaps
         c->hist_in ^= 1;
         c->cur ^= 1;
         c->cidx ^= 1;
-        c->frame += 1;
-        c->stats.path_samples += (uint64_t)c->cfg.width * (uint64_t)(c->own1 - c->own0);
+        c->frame += (uint32_t)g;
+        c->stats.path_samples += (uint64_t)g * (uint64_t)c->cfg.width * (uint64_t)(c->own1 - c->own0);
+        done += g;
     }
     return VRT_OK;
 }

@@ -22,9 +22,9 @@ hipError_t launch_prepare(hipStream_t st, const int8_t* mat, const uint8_t* rgb,
                           unsigned long long* l1, unsigned long long* l2);
 hipError_t query_render_residency(bool restir, bool instr, int* blocks_per_cu);
 hipError_t launch_render(hipStream_t st, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
-                         const PixelBuffers& out, unsigned* work_counter);
+                         const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples);
 hipError_t launch_gris(hipStream_t st, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1);
-hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1);
+hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1, int n_samples);
 hipError_t launch_tonemap(hipStream_t st, const FrameParams& fp, const f3* hdr, f4* ldr, int r0, int r1);
 hipError_t launch_detmath_probe(hipStream_t st, int op, int n, const float* a, const float* b, float* out);
 

@@ -84,7 +84,7 @@ __device__ __forceinline__ void flush_stats(const TraceStats& ts, Counters* c) {
 }
 
 template <bool RESTIR, bool INSTR>
-__global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_render(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, unsigned chunk) {
+__global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_render(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, unsigned chunk, int n_samples) {
     __shared__ unsigned long long s_l1[512];
     __shared__ unsigned long long s_l2[8];
     __shared__ float s_mats[128 * 14];
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_re
     const int lane = threadIdx.x & 63;
     const int tiles_x = (fp.W + 7) >> 3;
     const int tiles_y = (fp.row1 - fp.row0 + 7) >> 3;
-    const unsigned total = (unsigned)(tiles_x * tiles_y) * 64u;
+    // work items are (tile, sample, pixel-in-tile), 64 consecutive items = one 8x8 tile of one sample
+    const unsigned total = (unsigned)(tiles_x * tiles_y) * 64u * (unsigned)n_samples;
 
     Path<RESTIR> p;
     p.depth = -1;
@@ -131,11 +132,13 @@ __global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_re
             const unsigned my = chunk_next + rank;
             chunk_next += (n < avail) ? n : avail;
             if (need && rank < avail) {
-                const unsigned tile = my >> 6, in = my & 63u;
+                const unsigned group = my >> 6, in = my & 63u;
+                const unsigned tile = group / (unsigned)n_samples;
+                const int sample = (int)(group % (unsigned)n_samples);
                 const int u = (int)(tile % (unsigned)tiles_x) * 8 + (int)(in & 7u);
                 const int v = fp.row0 + (int)(tile / (unsigned)tiles_x) * 8 + (int)(in >> 3);
                 if (u < fp.W && v < fp.row1 && !outside_render_area(fp, (float)u, (float)v)) {
-                    path_begin(fp, p, u, v);
+                    path_begin(fp, p, u, v, sample);
                     local_idx = (v - fp.row0) * fp.W + u;
                 }
             }
@@ -176,10 +179,10 @@ __global__ __launch_bounds__(256) void k_gris(FrameParams fp, SceneData sc, Gris
 }
 
 // ---- temporal accumulation + presentation ------------------------------------------------------
-__global__ __launch_bounds__(256) void k_temporal(FrameParams fp, TemporalBuffers tb, int r0, int r1) {
+__global__ __launch_bounds__(256) void k_temporal(FrameParams fp, TemporalBuffers tb, int r0, int r1, int n_samples) {
     const int u = blockIdx.x * 64 + (threadIdx.x & 63);
     const int v = r0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (u < fp.W && v < r1) temporal_pixel(fp, tb, u, v);
+    if (u < fp.W && v < r1) temporal_pixel(fp, tb, u, v, n_samples);
 }
 __global__ __launch_bounds__(256) void k_tonemap(FrameParams fp, const f3* hdr, f4* ldr, int r0, int r1) {
     const int u = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -236,10 +239,10 @@ hipError_t query_render_residency(bool restir, bool instr, int* blocks_per_cu) {
 }
 
 hipError_t launch_render(hipStream_t st, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
-                         const PixelBuffers& out, unsigned* work_counters) {
+                         const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples) {
     // two counters alternate between launches: this launch counts on one and zeroes the other for the next launch
-    unsigned* work_counter = work_counters + (fp.frame & 1u);
-    unsigned* next_counter = work_counters + ((fp.frame + 1u) & 1u);
+    unsigned* work_counter = work_counters + (launch_seq & 1u);
+    unsigned* next_counter = work_counters + ((launch_seq + 1u) & 1u);
     dim3 g(n_blocks), b(VRT_RENDER_THREADS);
     // pixels a wave reserves per atomic: whole 8x8 tiles.  One tile keeps the tail short (measured: 192-pixel chunks
     // cost 13 % at 1080p on the sparse scene) and still cuts the atomic rate ~3x against per-refill atomics, which
@@ -247,11 +250,11 @@ hipError_t launch_render(hipStream_t st, bool restir, bool instr, int n_blocks, 
     unsigned chunk = 64u;
     if (const char* e = getenv("VRT_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 4096) chunk = (unsigned)(v / 64 * 64); }
     if (restir) {
-        if (instr) hipLaunchKernelGGL((k_render<true, true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk);
-        else hipLaunchKernelGGL((k_render<true, false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk);
+        if (instr) hipLaunchKernelGGL((k_render<true, true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk, n_samples);
+        else hipLaunchKernelGGL((k_render<true, false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk, n_samples);
     } else {
-        if (instr) hipLaunchKernelGGL((k_render<false, true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk);
-        else hipLaunchKernelGGL((k_render<false, false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk);
+        if (instr) hipLaunchKernelGGL((k_render<false, true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk, n_samples);
+        else hipLaunchKernelGGL((k_render<false, false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk, n_samples);
     }
     VRT_LAUNCH_CHECK();
     return hipSuccess;
@@ -263,9 +266,9 @@ hipError_t launch_gris(hipStream_t st, bool instr, const FrameParams& fp, const 
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1) {
+hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1, int n_samples) {
     dim3 g((fp.W + 63) / 64, (r1 - r0 + 3) / 4), b(256);
-    hipLaunchKernelGGL(k_temporal, g, b, 0, st, fp, tb, r0, r1);
+    hipLaunchKernelGGL(k_temporal, g, b, 0, st, fp, tb, r0, r1, n_samples);
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }

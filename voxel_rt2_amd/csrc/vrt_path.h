@@ -31,6 +31,7 @@ struct PixelBuffers {
     f3* gb_position;       // gbuff_position (:116)
     uint32_t* gb_mat;      // gbuff_mat_id (:112)
     struct ReservoirRec* reservoir;  // spatial_reservoirs[..., 0] (:108-109), only when ReSTIR is on
+    int sample_stride;     // elements between the colour / reflection-depth planes of consecutive fused samples
 };
 
 // reservoir.py:8-19 as a 64-byte record (f16 fields as binary16 codes)
@@ -129,10 +130,11 @@ struct NoRestir {};
 
 template <bool RESTIR>
 struct Path {
-    f3 pos, d, thr, contrib, nee_d, nee_s, primary_albedo;
+    f3 pos, d, thr, contrib, nee_d, nee_s, primary_albedo, primary_pos;
     float first_invpdf, refl_dist;
     uint32_t primary_mat_info;
     int pix_u, pix_v;     // global pixel coordinates
+    int sample;           // index of this sample inside a fused accumulate(n) launch (random-stream frame = fp.frame + sample)
     int depth;            // segment about to be traced; < 0 = lane holds no path
     int first_lobe;
     int sky_primary;
@@ -142,10 +144,12 @@ struct Path {
 
 // generate_new_sample + get_cast_dir (pathtracer.py:293-347)
 template <bool RESTIR>
-VRT_DEV void path_begin(const FrameParams& fp, Path<RESTIR>& p, int u, int v) {
+VRT_DEV void path_begin(const FrameParams& fp, Path<RESTIR>& p, int u, int v, int sample) {
     p.pix_u = u;
     p.pix_v = v;
-    p.rng = dm_rng_init(fp.seed, fp.frame, (uint32_t)(v * fp.W + u), 0u);
+    p.sample = sample;
+    p.primary_pos = mk3(0.0f);
+    p.rng = dm_rng_init(fp.seed, fp.frame + (uint32_t)sample, (uint32_t)(v * fp.W + u), 0u);
     f2 tc = pixel_texcoord(fp, (float)u, (float)v);
     if (fp.camera_is_moving == 0) { tc.x = tc.x + fp.taa_jitter.x * 0.5f; tc.y = tc.y + fp.taa_jitter.y * 0.5f; }
     f3 dv = norm3(screen_to_view(tc, 1.0f, fp.proj_inv));
@@ -190,10 +194,13 @@ VRT_DEV bool path_segment(const FrameParams& fp, const SceneData& sc, const PyrT
         p.primary_mat_info = pack_material(h.mat_id, h.albedo);
         p.primary_albedo = h.albedo;
         p.sky_primary = (h.closest == DM_INF) ? 1 : 0;
-        out.gb_normal[local_idx] = oct_encode(h.normal);
-        out.gb_position[local_idx] = ppos;
-        out.gb_mat[local_idx] = p.primary_mat_info;
-        out.gb_depth[local_idx] = view_to_screen(xform(fp.view, ppos, 1.0f), fp.proj).z;
+        p.primary_pos = ppos;
+        if (p.sample == 0) {  // the samples of one accumulate(n) call share camera and jitter: same primary vertex
+            out.gb_normal[local_idx] = oct_encode(h.normal);
+            out.gb_position[local_idx] = ppos;
+            out.gb_mat[local_idx] = p.primary_mat_info;
+            out.gb_depth[local_idx] = view_to_screen(xform(fp.view, ppos, 1.0f), fp.proj).z;
+        }
     } else if (depth == 1) {
         if (p.first_lobe != LOBE_DIFFUSE) p.refl_dist += h.closest;
         if constexpr (RESTIR) {
@@ -317,7 +324,8 @@ VRT_DEV void restir_finish(const FrameParams& fp, const SceneData& sc, const Pix
 template <bool RESTIR>
 VRT_DEV void path_finish(const FrameParams& fp, const SceneData& sc, const PixelBuffers& out, int local_idx, Path<RESTIR>& p,
                          TraceStats& ts) {
-    const f3 primary_pos = out.gb_position[local_idx];
+    const f3 primary_pos = p.primary_pos;
+    const int plane = local_idx + p.sample * out.sample_stride;
     // virtual reflection depth (543-547)
     float refl = 0.0f;
     if (p.refl_dist != 0.0f) {
@@ -325,7 +333,7 @@ VRT_DEV void path_finish(const FrameParams& fp, const SceneData& sc, const Pixel
         const f3 vp = primary_pos + pdir * p.refl_dist;
         refl = linearize_depth(view_to_screen(xform(fp.view, vp, 1.0f), fp.proj).z, fp.proj_inv);
     }
-    out.gb_refl_depth[local_idx] = refl;
+    out.gb_refl_depth[plane] = refl;
 
     f3 diffuse = mk3(0.0f), specular = mk3(0.0f);
     if constexpr (!RESTIR) {
@@ -339,8 +347,8 @@ VRT_DEV void path_finish(const FrameParams& fp, const SceneData& sc, const Pixel
     } else {
         restir_finish(fp, sc, out, local_idx, p, primary_pos, diffuse, specular, ts);
     }
-    out.color_d[local_idx] = diffuse;
-    out.color_s[local_idx] = specular;
+    out.color_d[plane] = diffuse;
+    out.color_s[plane] = specular;
 }
 
 }  // namespace vrt

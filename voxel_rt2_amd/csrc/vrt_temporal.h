@@ -35,6 +35,8 @@ struct TemporalBuffers {
     const uint32_t* prev_normal;  // gbuff_prev_normals / gbuff_prev_depth
     const float* prev_depth;
     f3* hdr;                      // color_buffer after accumulate(); becomes the next pass's render target
+    int sample_stride;            // elements between the planes of consecutive fused samples (colours, raw reflection depth)
+    mat4 prev_view, prev_proj;    // prev_view_mat / prev_proj_mat (pathtracer.py:103-104, 283-287)
 };
 
 VRT_DEV f3 scrub(f3 c) {  // pathtracer.py:1069-1075
@@ -63,8 +65,8 @@ VRT_DEV f3 bilinear_color(const FrameParams& fp, const f3* buf, f2 uv) {
     f3 tl = scrub(buf[clamped_index(fp, ix, iy + 1)]), tr = scrub(buf[clamped_index(fp, ix + 1, iy + 1)]);
     return lerp3(lerp3(bl, br, fx), lerp3(tl, tr, fx), fy);
 }
-VRT_DEV f3 reproject(const FrameParams& fp, f3 wp) {  // pathtracer.py:993-1000
-    f4 p = mul4(fp.prev_proj, mul4(fp.prev_view, mk4(wp.x, wp.y, wp.z, 1.0f)));
+VRT_DEV f3 reproject(const FrameParams& fp, const TemporalBuffers& tb, f3 wp) {  // pathtracer.py:993-1000
+    f4 p = mul4(tb.prev_proj, mul4(tb.prev_view, mk4(wp.x, wp.y, wp.z, 1.0f)));
     return mk3(p.x / p.w, p.y / p.w, p.z / p.w) * 0.5f + 0.5f;
 }
 VRT_DEV float catmullrom(float x) {  // pathtracer.py:1002-1014
@@ -125,8 +127,10 @@ VRT_DEV void blend_history(const FrameParams& fp, float wsum, f4& h, f3 cur) {  
     }
 }
 
-// One pixel (u, v) of this shard's rows.
-VRT_DEV void temporal_pixel(const FrameParams& fp, const TemporalBuffers& tb, int u, int v) {
+// One pixel (u, v) of this shard's rows.  n_samples > 1: the samples of one accumulate(n) call, rendered by one
+// fused k_render launch into consecutive planes (static camera only): the running means are advanced n times in
+// registers, in sample order, exactly as n separate passes would, and the histories / HDR are written once.
+VRT_DEV void temporal_pixel(const FrameParams& fp, const TemporalBuffers& tb, int u, int v, int n_samples) {
     const int idx = (v - fp.row0) * fp.W + u;
     if (outside_render_area(fp, (float)u, (float)v)) {
         // not rendered at this render_scale: the reference leaves color_buffer (= the last HDR value) untouched.
@@ -138,6 +142,7 @@ VRT_DEV void temporal_pixel(const FrameParams& fp, const TemporalBuffers& tb, in
     }
     int rx, ry;
     render_res(fp, rx, ry);
+    const int last = (n_samples - 1) * tb.sample_stride;  // plane of the last sample
 
     // prepass: reflection-depth average over the valid taps of a 4x4 window (:1040-1066)
     float rsum = 0.0f, rcount = 0.0f;
@@ -146,7 +151,7 @@ VRT_DEV void temporal_pixel(const FrameParams& fp, const TemporalBuffers& tb, in
             int tx = u + x, ty = v + y;
             if (tx < 0 || ty < 0 || tx > rx - 1 || ty > ry - 1) continue;
             if (ty < fp.row0 || ty >= fp.row1) continue;  // beyond the shard's halo (reflection depth is unused there)
-            float rd = tb.gb_refl_raw[(ty - fp.row0) * fp.W + tx];
+            float rd = tb.gb_refl_raw[last + (ty - fp.row0) * fp.W + tx];
             if (rd != 0.0f) { rcount += 1.0f; rsum += rd; }
         }
     const float refl_depth = (rcount > 0.01f) ? rsum / rcount : 0.0f;
@@ -156,29 +161,34 @@ VRT_DEV void temporal_pixel(const FrameParams& fp, const TemporalBuffers& tb, in
     const float nl_depth = tb.gb_depth[idx];
     const f3 x1 = xform(fp.view_inv, screen_to_view(tc, nl_depth, fp.proj_inv), 1.0f);
     if (near_zero3(x1)) {  // both filters `continue`: colour stays the scrubbed diffuse sample, histories persist
-        tb.hdr[idx] = scrub(tb.color_d[idx]);
+        tb.hdr[idx] = scrub(tb.color_d[last + idx]);
         tb.hist_d_out[idx] = tb.hist_d_in[idx];
         tb.hist_s_out[idx] = tb.hist_s_in[idx];
         return;
     }
-    const f3 cur_d = bilinear_color(fp, tb.color_d, tc);
-    const f3 cur_s = bilinear_color(fp, tb.color_s, tc);
     f4 hd, hs;
-    float wd = 1.0f, ws = 1.0f;
     if (fp.camera_is_moving == 0) {
         hd = tb.hist_d_in[idx];
         hs = tb.hist_s_in[idx];
+        for (int k = 0; k < n_samples; k++) {
+            const f3 cur_d = bilinear_color(fp, tb.color_d + k * tb.sample_stride, tc);
+            const f3 cur_s = bilinear_color(fp, tb.color_s + k * tb.sample_stride, tc);
+            blend_history(fp, 1.0f, hd, cur_d);
+            blend_history(fp, 1.0f, hs, cur_s);
+        }
     } else {
+        const f3 cur_d = bilinear_color(fp, tb.color_d, tc);
+        const f3 cur_s = bilinear_color(fp, tb.color_s, tc);
         const f3 n1 = oct_decode(tb.gb_normal[idx]);
-        f3 rp = reproject(fp, x1);
-        wd = history_resample<true>(fp, tb, tb.hist_d_in, mk2(rp.x, rp.y), linearize_depth(rp.z, fp.proj_inv), n1, hd);
+        f3 rp = reproject(fp, tb, x1);
+        float wd = history_resample<true>(fp, tb, tb.hist_d_in, mk2(rp.x, rp.y), linearize_depth(rp.z, fp.proj_inv), n1, hd);
         float nl = delinearize_depth(refl_depth, fp.proj);
         f3 refl_pos = xform(fp.view_inv, screen_to_view(tc, nl, fp.proj_inv), 1.0f);
-        f3 rps = reproject(fp, (refl_depth != 0.0f) ? refl_pos : x1);
-        ws = history_resample<false>(fp, tb, tb.hist_s_in, mk2(rps.x, rps.y), linearize_depth(rps.z, fp.proj_inv), n1, hs);
+        f3 rps = reproject(fp, tb, (refl_depth != 0.0f) ? refl_pos : x1);
+        float ws = history_resample<false>(fp, tb, tb.hist_s_in, mk2(rps.x, rps.y), linearize_depth(rps.z, fp.proj_inv), n1, hs);
+        blend_history(fp, wd, hd, cur_d);
+        blend_history(fp, ws, hs, cur_s);
     }
-    blend_history(fp, wd, hd, cur_d);
-    blend_history(fp, ws, hs, cur_s);
     tb.hist_d_out[idx] = hd;
     tb.hist_s_out[idx] = hs;
     f3 col = mk3(hd.x, hd.y, hd.z);

@@ -102,7 +102,7 @@ struct SkyTables {
 
 // Everything the per-pixel kernels read that is not a per-pixel buffer.  Passed by value.
 struct FrameParams {
-    mat4 view, proj, view_inv, proj_inv, prev_view, prev_proj;
+    mat4 view, proj, view_inv, proj_inv;
     f3 camera_pos;
     f2 taa_jitter;
     f2 inv_res;
