@@ -103,27 +103,50 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+    from voxel_rt2_amd import parallel
     mat, rgb, params = scenes.scene_s1(0)
-    rows = split_rows(HEIGHT, world)[rank]
-    cfg = host.make_config(WIDTH, HEIGHT, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=MAX_DEPTH,
-                           seed=SEED, device=local_rank, rows=rows if world > 1 else None)
     lib = _lib.load()
-    sess = NativeSession(lib, "vrt_", cfg)
-    setup_session(sess, mat, rgb, params)
+    stream = torch.cuda.Stream()  # rendering, tile copy and the RCCL gather are all ordered on this one stream
+
+    def make_session(rows):
+        cfg = host.make_config(WIDTH, HEIGHT, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=MAX_DEPTH,
+                               seed=SEED, device=local_rank, rows=rows if world > 1 else None)
+        s = NativeSession(lib, "vrt_", cfg)
+        s.set_stream(stream.cuda_stream)
+        setup_session(s, mat, rgb, params)
+        return s
+
+    # Row tiles: start from an equal split, then (untimed) let every rank measure its tile's device time and move the
+    # tile boundaries so that all ranks carry the same cost -- the sky rows of this scene cost a fraction of the floor rows.
+    bounds = split_rows(HEIGHT, world)
+    sess = make_session(bounds[rank])
+    for _ in range(2 if world > 1 else 0):
+        sess.accumulate(SPP_PER_STEP)
+        lib.vrt_reset_stats(C.c_void_p(sess._ctx))
+        sess.accumulate(SPP_PER_STEP)
+        st0 = sess.stats()
+        mine = torch.tensor([st0["render_ms"] + st0["temporal_ms"]], dtype=torch.float64, device="cuda")
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        bounds = parallel.rebalance_rows(bounds, [float(t.item()) for t in allc], HEIGHT)
+        sess.close()
+        sess = make_session(bounds[rank])
+    rows = bounds[rank]
 
     # gather plumbing: equal-sized tiles (padded to the tallest tile), torch owns the staging tensors
-    max_rows = max(b - a for a, b in split_rows(HEIGHT, world))
+    max_rows = max(b - a for a, b in bounds)
     tile = torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device="cuda")
     gathered = [torch.zeros_like(tile) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def step():
-        sess.accumulate(SPP_PER_STEP)
-        if world > 1:
-            sess.fetch_hdr_device(tile.data_ptr())  # D2D on the library's stream, returns when done
-            dist.gather(tile, gathered, dst=0)
+        with torch.cuda.stream(stream):
+            sess.accumulate(SPP_PER_STEP)
+            if world > 1:
+                sess.fetch_hdr_device_async(tile.data_ptr())  # D2D, queued behind the kernels
+                dist.gather(tile, gathered, dst=0)
 
     def fence():
-        sess.sync()
+        stream.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -163,7 +186,8 @@ def main():
         bytes_per_sample = 4.0 * q + 60.0 * hc + 96.0 * ls + 52.0
         launches = max(st["render_launches"], 1)
         avg_ms = st["render_ms"] / launches
-        achieved = bytes_per_sample * own_px / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        samples_per_launch = st["path_samples"] / launches  # a launch renders own_px pixels x the fused samples
+        achieved = bytes_per_sample * samples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
@@ -177,12 +201,13 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "example1-style scene S1 (scenes.scene_s1), 128^3 grid, 1920x1080, 4 spp/step, 8 bounces, "
                                    "static camera, ReSTIR off", "width": WIDTH, "height": HEIGHT, "spp_per_step": SPP_PER_STEP,
-                       "max_depth": MAX_DEPTH, "seed": SEED, "sharding": f"{world} contiguous row tile(s) + RCCL gather" if world > 1 else "none"},
+                       "max_depth": MAX_DEPTH, "seed": SEED, "sharding": (f"{world} contiguous row tiles, boundaries balanced by measured tile cost, RCCL gather per step; "
+                                    f"tile rows {[b - a for a, b in bounds]}") if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "k_render", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_path_sample": round(bytes_per_sample, 2),
                          "queries_per_path_sample": round(q, 2), "closest_hits_per_path_sample": round(hc, 3),
-                         "render_ms_per_launch": round(avg_ms, 4),
+                         "path_samples_per_launch": int(samples_per_launch), "render_ms_per_launch": round(avg_ms, 4),
                          "temporal_ms_per_launch": round(st["temporal_ms"] / max(st["temporal_launches"], 1), 4)},
         }
         if not args.no_cpu_baseline and world == 1:

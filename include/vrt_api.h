@@ -133,6 +133,12 @@ int vrt_fetch_hdr(vrt_ctx* ctx, float* out);
 /* same, this context's rows only, copied device-to-device into caller-owned device memory
  * (f32[row_end-row_begin][W][3]); the call returns after the copy completed. */
 int vrt_fetch_hdr_device(vrt_ctx* ctx, void* device_ptr);
+/* same copy, only queued on the context's stream (no host synchronisation) */
+int vrt_fetch_hdr_device_async(vrt_ctx* ctx, void* device_ptr);
+/* Queue all further work of this context on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream),
+ * so that rendering, the tile copy and a following RCCL collective are ordered on the device without host
+ * round trips; NULL returns to a private stream.  The stream must outlive the context or be reset first. */
+int vrt_set_stream(vrt_ctx* ctx, void* hip_stream);
 /* Renderer.fetch_image (pathtracer.py:1321-1323, 634-662): LDR rgba f32[H][W][4] */
 int vrt_fetch_ldr(vrt_ctx* ctx, float* out);
 int vrt_fetch_buffer(vrt_ctx* ctx, int which, void* out);

@@ -73,6 +73,8 @@ def declare(lib, prefix):
     sig("end_frame", C.c_int, P)
     sig("fetch_hdr", C.c_int, P, P)
     sig("fetch_hdr_device", C.c_int, P, P)
+    sig("fetch_hdr_device_async", C.c_int, P, P)
+    sig("set_stream", C.c_int, P, P)
     sig("fetch_ldr", C.c_int, P, P)
     sig("fetch_buffer", C.c_int, P, C.c_int, P)
     sig("sync", C.c_int, P)

@@ -110,6 +110,12 @@ class NativeSession:
     def fetch_hdr_device(self, device_ptr):
         self._call("fetch_hdr_device", C.c_void_p(int(device_ptr)))
 
+    def fetch_hdr_device_async(self, device_ptr):
+        self._call("fetch_hdr_device_async", C.c_void_p(int(device_ptr)))
+
+    def set_stream(self, hip_stream):
+        self._call("set_stream", C.c_void_p(int(hip_stream) if hip_stream else None))
+
     def fetch_ldr(self):
         out = np.empty((self.H, self.W, 4), dtype=np.float32)
         self._call("fetch_ldr", out.ctypes.data_as(C.c_void_p))

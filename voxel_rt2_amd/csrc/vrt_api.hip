@@ -37,6 +37,7 @@ struct vrt_ctx {
     bool instrumented = false;
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;
     int n_cu = 0, render_blocks = 0;
     // rows
     int own0 = 0, own1 = 0;   // rows this context produces
@@ -251,7 +252,7 @@ void vrt_destroy(vrt_ctx* c) {
                     c->d_ldr, c->d_res[0], c->d_res[1], c->d_multi_d};
     for (void* p : ptrs)
         if (p) hipFree(p);
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->stream && c->owns_stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -482,6 +483,24 @@ int vrt_fetch_hdr_device(vrt_ctx* c, void* device_ptr) {
     const char* src = (const char*)c->d_cbuf[c->cidx] + (size_t)(c->own0 - c->buf0) * W * sizeof(f3);
     HIP_TRY(hipMemcpyAsync(device_ptr, src, (size_t)(c->own1 - c->own0) * W * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return VRT_OK;
+}
+int vrt_fetch_hdr_device_async(vrt_ctx* c, void* device_ptr) {
+    if (!c || !device_ptr) return fail(VRT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t W = c->cfg.width;
+    const char* src = (const char*)c->d_cbuf[c->cidx] + (size_t)(c->own0 - c->buf0) * W * sizeof(f3);
+    HIP_TRY(hipMemcpyAsync(device_ptr, src, (size_t)(c->own1 - c->own0) * W * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
+    return VRT_OK;
+}
+int vrt_set_stream(vrt_ctx* c, void* hip_stream) {
+    if (!c) return fail(VRT_E_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    resolve_events(c);
+    if (c->owns_stream && c->stream) hipStreamDestroy(c->stream);
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->owns_stream = false; }
+    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->owns_stream = true; }
     return VRT_OK;
 }
 int vrt_fetch_ldr(vrt_ctx* c, float* out) {

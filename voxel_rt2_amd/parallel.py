@@ -35,3 +35,24 @@ def gather_frame(tile, height, width, rank, world_size, dst=0, out_list=None):
     for r, (a, b) in enumerate(split_rows(height, world_size)):
         frame[a:b] = out_list[r][: b - a]
     return frame
+
+
+def rebalance_rows(bounds, costs, height, min_rows=8):
+    """New contiguous row ranges with (approximately) equal cost, given the cost each rank measured on its current
+    range (piecewise-constant cost density per row).  Rows are the unit; every rank keeps at least `min_rows`."""
+    n = len(bounds)
+    if n == 1:
+        return [(0, height)]
+    dens = np.zeros(height, dtype=np.float64)
+    for (a, b), c in zip(bounds, costs):
+        dens[a:b] = max(float(c), 1e-9) / max(b - a, 1)
+    cum = np.concatenate([[0.0], np.cumsum(dens)])
+    edges = [0]
+    for k in range(1, n):
+        target = cum[-1] * k / n
+        e = int(np.searchsorted(cum, target))
+        e = max(e, edges[-1] + min_rows)
+        e = min(e, height - (n - k) * min_rows)
+        edges.append(e)
+    edges.append(height)
+    return [(edges[i], edges[i + 1]) for i in range(n)]
