@@ -20,6 +20,8 @@ CASES = [
     dict(name="config4_dense_4k_d8_1gpu", scene="dense", W=3840, H=2160, depth=8, spp=4, steps=4),
     dict(name="config3_s6_sky_clouds_restir_1080p_d8", scene="s6", W=1920, H=1080, depth=8, spp=4, steps=5, restir=True, sky_res=3840),
     dict(name="s6_sky_clouds_1080p_d8_norestir", scene="s6", W=1920, H=1080, depth=8, spp=4, steps=5, sky_res=3840),
+    dict(name="sunlit_restir_1080p_d8", scene="sunlit", W=1920, H=1080, depth=8, spp=4, steps=5, restir=True),
+    dict(name="s6_nosky_restir_1080p_d8", scene="s6", W=1920, H=1080, depth=8, spp=4, steps=5, restir=True),
 ]
 
 

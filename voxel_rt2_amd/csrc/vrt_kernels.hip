@@ -160,7 +160,10 @@ __global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_re
 
 // ---- spatial reuse ---------------------------------------------------------------------------
 template <bool INSTR>
-__global__ __launch_bounds__(256) void k_gris(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r1) {
+#ifndef VRT_GRIS_MIN_WAVES
+#define VRT_GRIS_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES) void k_gris(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r1) {
     __shared__ unsigned long long s_l1[512];
     __shared__ unsigned long long s_l2[8];
     for (int i = threadIdx.x; i < 512; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];

@@ -141,14 +141,17 @@ VRT_DEV Material material_from_bits(const float* mats, uint32_t enc, int& id) { 
     return m;
 }
 
-// pathtracer.py:672-812: shift `src`'s sample to the primary vertex (dst_pos, dst_normal, dst_mat)
-VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, f3 dst_pos, f3 dst_normal, const Material& dst_mat,
+// pathtracer.py:672-812: shift `src`'s sample to the primary vertex at dst_pos whose shading frame is `ds`
+// (normal, material, view direction toward the camera -- built by the caller so the centre pixel's frame, which is
+// the destination of every neighbour's shift, is set up once per pixel instead of once per tap)
+VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, f3 dst_pos, const Surf& ds,
                           const Reservoir& src, f3& out_d, f3& out_s, float& out_jac, TraceStats& ts) {
     const bool escape = near_zero3(src.z.rc_normal);
     const bool last = near_zero3(src.z.rc_incident_dir);
     const bool nee_vis = !near_zero3(src.z.rc_nee_dir);
     const f3 to_rc = escape ? src.z.rc_pos : norm3(src.z.rc_pos - dst_pos);
     float passed = 1.0f;
+    const f3 dst_normal = ds.n;
     if (dot3(dst_normal, to_rc) < 1e-5f || (!escape && dot3(src.z.rc_normal, -to_rc) < 1e-5f)) passed = 0.0f;
 
     int rc_id;
@@ -180,8 +183,6 @@ VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, f3 dst_pos
     }
     contrib = contrib + ((rc_id != 2) ? mk3(0.0f) : rc_mat.base);
 
-    Surf ds;
-    surf_init(ds, dst_mat, dst_normal, norm3(fp.camera_pos - dst_pos));
     f3 pd, ps;
     eval_lobes(ds, to_rc, src.z.lobes % 10, pd, ps);
     const float c = dm_saturate(dot3(dst_normal, to_rc));
@@ -256,10 +257,18 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     }
     int cmat_id;
     const Material cmat = material_from_bits(sc.mats, gb.gb_mat[idx], cmat_id);
+    Surf cds;  // the centre pixel's shading frame (pathtracer.py:731-732 with dst = centre)
+    surf_init(cds, cmat, cn1, norm3(fp.camera_pos - cx1));
     int valid = 0;
     float canonical_mis = 1.0f;
     f3 chosen_d = mk3(0.0f), chosen_s = mk3(0.0f);
 
+    // The reference's tap loop does two independent things per accepted tap: (1) shift the CENTRE sample into the
+    // neighbour's domain to grow the canonical MIS weight (:917-931), (2) shift the NEIGHBOUR's sample into the centre's
+    // domain and stream it through the output reservoir (:922-956).  (1) only sums into canonical_mis, (2) only draws
+    // from the random stream; run as two loops over the same taps, in tap order, every sum and draw keeps its place
+    // while each loop carries one shift's worth of live state instead of two (k_gris is register bound).
+    unsigned accepted = 0u;  // max_taps <= 32
     for (int i = 0; i < max_taps; i++) {
         const float golden = 2.399963229728f;
         float angle = ((float)i + angle_shift) * golden;
@@ -275,22 +284,35 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         const f3 nn1 = oct_decode(gb.gb_normal[t]);
         const f3 nx1 = xform(fp.view_inv, screen_to_view(ttc, gb.gb_depth[t], fp.proj_inv), 1.0f);
         const float ndist = len3(nx1 - fp.camera_pos);
+        if (dm_abs(ndist - cdist) > 0.1f * cdist || dot3(cn1, nn1) < 0.5f) continue;  // :912
+        accepted |= 1u << i;
+        const float nb_M = dm_f16_to_f32((uint16_t)(gb.res_in[t].M_W & 0xffffu));
+        int nmat_id;
+        const Material nmat = material_from_bits(sc.mats, gb.gb_mat[t], nmat_id);
+        f3 cd, cs;
+        float cjac;
+        Surf nds;
+        surf_init(nds, nmat, nn1, norm3(fp.camera_pos - nx1));
+        shift_sample(fp, sc, nx1, nds, center, cd, cs, cjac, ts);
+        float c_p_hat = lum(cd + cs) * cjac;
+        float cw = c_p_hat * nb_M;
+        cw /= c_p_hat * nb_M + lum(center.z.F) * center.M / (float)max_taps;
+        canonical_mis += 1.0f - cw;
+    }
+    for (int i = 0; i < max_taps; i++) {
+        if (((accepted >> i) & 1u) == 0u) continue;
+        const float golden = 2.399963229728f;
+        float angle = ((float)i + angle_shift) * golden;
+        float rad = dm_sqrt(((float)i + radius_shift) / (float)max_taps) * max_radius;
+        float sa, ca;
+        dm_sincos(angle, &sa, &ca);
+        const int t = (v + dm_f2i(sa * rad) - fp.row0) * fp.W + u + dm_f2i(ca * rad);
         Reservoir nb;
         reservoir_init(nb);
         reservoir_decode(nb, gb.res_in[t]);
-        if (dm_abs(ndist - cdist) > 0.1f * cdist || dot3(cn1, nn1) < 0.5f) continue;
-        int nmat_id;
-        const Material nmat = material_from_bits(sc.mats, gb.gb_mat[t], nmat_id);
-
-        f3 cd, cs, sd, ss;
-        float cjac, jac;
-        shift_sample(fp, sc, nx1, nn1, nmat, center, cd, cs, cjac, ts);
-        shift_sample(fp, sc, cx1, cn1, cmat, nb, sd, ss, jac, ts);
-
-        float c_p_hat = lum(cd + cs) * cjac;
-        float cw = c_p_hat * nb.M;
-        cw /= c_p_hat * nb.M + lum(center.z.F) * center.M / (float)max_taps;
-        canonical_mis += 1.0f - cw;
+        f3 sd, ss;
+        float jac;
+        shift_sample(fp, sc, cx1, cds, nb, sd, ss, jac, ts);
 
         float p_hat = lum(sd + ss);
         float p_hat_n = p_hat / jac;
