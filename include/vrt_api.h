@@ -154,6 +154,10 @@ int vrt_set_instrumented(vrt_ctx* ctx, int on);
  * op 0 sin 1 cos 2 exp 3 log 4 pow 5 acos 6 atan2 7 min 8 max 9 f16 round trip 10 a/b 11 sqrt
  * 12 a*b+a (uncontracted) 13 float->int. */
 int vrt_detmath_probe(int device, int op, int n, const float* a, const float* b, float* out);
+/* Diagnostic builds only (library compiled with -DVRT_DIAG_REGIONS, see tools/diag_regions.py): copy out the
+ * 32 x {wave entries, active lanes} counters of the instrumented regions of the render kernel and optionally
+ * zero them.  The shipped library returns VRT_E_STATE -- it carries no region counters. */
+int vrt_diag_regions(vrt_ctx* ctx, unsigned long long* out64, int reset);
 
 #ifdef __cplusplus
 }

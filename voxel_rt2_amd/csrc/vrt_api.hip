@@ -561,6 +561,19 @@ int vrt_reset_stats(vrt_ctx* c) {
     memset(&c->stats, 0, sizeof(c->stats));
     return VRT_OK;
 }
+// diagnostic builds (-DVRT_DIAG_REGIONS) only: 32 x {wave entries, active lanes} per instrumented code region
+int vrt_diag_regions(vrt_ctx* c, unsigned long long* out64, int reset) {
+    if (!c || !out64) return fail(VRT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 64 * sizeof(unsigned long long)));
+    hipError_t e = launch_diag_read(c->stream, d, reset);
+    if (e != hipSuccess) { hipFree(d); return fail(VRT_E_STATE, "library was not built with VRT_DIAG_REGIONS"); }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out64, d, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    hipFree(d);
+    return VRT_OK;
+}
 // runs op over n floats on the device: checks the numeric contract of vrt_detmath.h on gfx950
 int vrt_detmath_probe(int device, int op, int n, const float* a, const float* b, float* out) {
     if (n <= 0 || !a || !b || !out) return fail(VRT_E_INVALID, "bad argument");

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_re
                 const int u = (int)(tile % (unsigned)tiles_x) * 8 + (int)(in & 7u);
                 const int v = fp.row0 + (int)(tile / (unsigned)tiles_x) * 8 + (int)(in >> 3);
                 if (u < fp.W && v < fp.row1 && !outside_render_area(fp, (float)u, (float)v)) {
+                    VRT_REGION(0);
                     path_begin(fp, p, u, v, sample);
                     local_idx = (v - fp.row0) * fp.W + u;
                 }
@@ -191,6 +192,21 @@ __global__ __launch_bounds__(256) void k_tonemap(FrameParams fp, const f3* hdr, 
     const int u = blockIdx.x * 64 + (threadIdx.x & 63);
     const int v = r0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (u < fp.W && v < r1) ldr[(v - fp.row0) * fp.W + u] = tonemap_pixel(fp, hdr, u, v);
+}
+#if defined(VRT_DIAG_REGIONS)
+__global__ void k_diag_read(unsigned long long* out, int reset) {
+    int i = threadIdx.x;
+    if (i < 64) { out[i] = g_vrt_region[i]; if (reset) g_vrt_region[i] = 0ULL; }
+}
+#endif
+hipError_t launch_diag_read(hipStream_t st, unsigned long long* out, int reset) {
+#if defined(VRT_DIAG_REGIONS)
+    hipLaunchKernelGGL(k_diag_read, dim3(1), dim3(64), 0, st, out, reset);
+    return hipGetLastError();
+#else
+    (void)st; (void)out; (void)reset;
+    return hipErrorNotSupported;
+#endif
 }
 __global__ void k_detmath_probe(int op, int n, const float* a, const float* b, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -189,6 +189,7 @@ VRT_DEV bool path_segment(const FrameParams& fp, const SceneData& sc, const PyrT
     const bool surface = (!h.hit_light) && (h.closest < DM_INF);
 
     if (depth == 0) {
+        VRT_REGION(8);
         // g-buffer of the primary vertex (pathtracer.py:403-407, 535-541); sky pixels store position 0 (:510)
         const f3 ppos = (h.closest == DM_INF) ? mk3(0.0f) : hit_pos;
         p.primary_mat_info = pack_material(h.mat_id, h.albedo);
@@ -214,6 +215,7 @@ VRT_DEV bool path_segment(const FrameParams& fp, const SceneData& sc, const PyrT
     }
 
     if (surface) {
+        VRT_REGION(2);
         p.pos = hit_pos + h.normal * VRT_EPS;
         Material m = load_material(sc.mats, h.mat_id);
         m.base = h.albedo;
@@ -240,6 +242,7 @@ VRT_DEV bool path_segment(const FrameParams& fp, const SceneData& sc, const PyrT
         float pdf = 1.0f, bounce_light_pdf = 0.0f;
         int lobe = 0;
         if (!final_segment) {
+            VRT_REGION(10);
             next_d = sample_bsdf(s, p.rng, brdf, pdf, lobe);
             bounce_light_pdf = cone_pdf(fp.light_cos_max, dot3(fp.light_dir, next_d));
         }
@@ -251,6 +254,7 @@ VRT_DEV bool path_segment(const FrameParams& fp, const SceneData& sc, const PyrT
                 nee_visible = 1.0f;
                 if constexpr (RESTIR) { if (depth == 1) p.rs.rc_nee_dir = ldir; }
                 if (RESTIR || light_on) {
+                    VRT_REGION(4);
                     const float light_bsdf_pdf = pdf_all(s, ldir);
                     float w = 1.0f;
                     if (depth > 0) w = power_heuristic(cone_pdf(fp.light_cos_max, 1.0f), light_bsdf_pdf);
@@ -297,6 +301,7 @@ VRT_DEV bool path_segment(const FrameParams& fp, const SceneData& sc, const PyrT
     }
 
     if (h.closest == DM_INF) {
+        VRT_REGION(5);
         // escaped: background colour or skybox, plus the sun disc (pathtracer.py:500-517)
         const float hit_sun = (dot3(fp.light_dir, p.d) >= fp.light_cos_max) ? 1.0f : 0.0f;
         f3 scat = fp.background, trans = mk3(1.0f);
@@ -324,6 +329,7 @@ VRT_DEV void restir_finish(const FrameParams& fp, const SceneData& sc, const Pix
 template <bool RESTIR>
 VRT_DEV void path_finish(const FrameParams& fp, const SceneData& sc, const PixelBuffers& out, int local_idx, Path<RESTIR>& p,
                          TraceStats& ts) {
+    VRT_REGION(6);
     const f3 primary_pos = p.primary_pos;
     const int plane = local_idx + p.sample * out.sample_stride;
     // virtual reflection depth (543-547)

@@ -116,6 +116,7 @@ VRT_DEV void raytrace(const PyrT& P, f3 o, f3 d, TraceOut& r, int& queries) {
             if (hit_distance > far) { hit_distance = DM_INF; break; }
             bool solid;
             int nq;
+            VRT_REGION(1);
             lod = descend(P, ix, iy, iz, lod, solid, bc, nq);
             queries += nq;
             if (solid) break;
@@ -181,6 +182,7 @@ VRT_DEV void next_hit(const FrameParams& fp, const SceneData& sc, const PyrT& P,
     int nq;
     raytrace(P, eye, d, tr, nq);
     ts.rays += 1u; ts.iters += (unsigned)tr.iters; ts.queries += (unsigned)nq;
+    VRT_REGION(SHADOW ? 3 : 9);  // ray set-up + result (one entry per ray)
     if (tr.dist * voxel_size < h.closest) {
         h.closest = tr.dist * voxel_size;
         if (!SHADOW) {

@@ -70,6 +70,26 @@ VRT_DEV f4 mul4(const mat4& M, f4 v) {
 }
 
 #define VRT_EPS 1e-6f
+
+// Diagnostic build only (-DVRT_DIAG_REGIONS): per code region, how many times a WAVE entered it and with how many
+// active lanes -- where the issue slots of the divergent render kernel go.  Never defined in the shipped library.
+#if defined(VRT_DIAG_REGIONS) && defined(__HIPCC__)
+static __device__ unsigned long long g_vrt_region[64];
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VRT_REGION(id)                                                                                              \
+    do {                                                                                                            \
+        unsigned long long m_ = __ballot(1);                                                                        \
+        if ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (int)__ffsll((long long)m_) - 1) { \
+            atomicAdd(&g_vrt_region[2 * (id)], 1ULL);                                                               \
+            atomicAdd(&g_vrt_region[2 * (id) + 1], (unsigned long long)__popcll(m_));                               \
+        }                                                                                                           \
+    } while (0)
+#else
+#define VRT_REGION(id) ((void)0)
+#endif
+#else
+#define VRT_REGION(id) ((void)0)
+#endif
 #define VRT_GRID 128
 
 // One Disney material row (14 f32, the order of the host table).
