@@ -11,6 +11,8 @@
 #include "../../voxel_rt2_amd/csrc/vrt_bsdf.h"
 #include "../../voxel_rt2_amd/csrc/vrt_sky.h"
 #include "../../voxel_rt2_amd/csrc/vrt_path.h"
+#include "../../voxel_rt2_amd/csrc/vrt_pool.h"
+#include <cstdlib>
 #include "../../voxel_rt2_amd/csrc/vrt_restir.h"
 #include "../../voxel_rt2_amd/csrc/vrt_temporal.h"
 
@@ -149,6 +151,43 @@ static void render_all(Emu* c, const FrameParams& fp, const SceneData& sc, const
         }
 }
 
+// The pool kernel's stage functions (vrt_pool.h) stepped one path at a time: the record goes through the same
+// packed slot (here a 25-dword array) and scratch line as on the device, and every walk is suspended and
+// resumed every third step so that the packing of a half-done walk is exercised too.
+static void render_all_pool(Emu* c, const FrameParams& fp, const SceneData& sc, const PixelBuffers& out) {
+    GlobalPyramid P;
+    P.p = sc.pyr;
+    for (int v = fp.row0; v < fp.row1; v++)
+        for (int u = 0; u < fp.W; u++) {
+            if (outside_render_area(fp, (float)u, (float)v)) continue;
+            uint32_t slot[PF_COUNT] = {0}, cold[PC_COUNT] = {0};
+            SlotRef s{slot, 1};
+            int st = pool_begin(fp, s, u, v, 0, c->ts);
+            while (st != SLOT_EMPTY) {
+                if (st == SLOT_RAY) {
+                    RayWalk w;
+                    walk_load(s, w);
+                    BrickCache bc{-1, 0ULL};
+                    const int iters0 = w.iters;
+                    for (int k = 1;; k++) {
+                        int nq;
+                        const bool fin = walk_trip(P, w, bc, nq);
+                        c->ts.queries += (unsigned)nq;
+                        if (fin) break;
+                        if (k % 3 == 0) { walk_store(s, w); walk_load(s, w); bc.key = -1; }
+                    }
+                    c->ts.iters += (unsigned)(w.iters - iters0);
+                    walk_store(s, w);
+                    st = slot_state_after_walk(w.t, s.f(PF_FLOOR_T));
+                } else if (st == SLOT_SHADE) {
+                    st = pool_shade<HIT_SOMETHING>(fp, sc, P, out, s, cold, c->ts);
+                } else {
+                    st = pool_shade<HIT_NOTHING>(fp, sc, P, out, s, cold, c->ts);
+                }
+            }
+        }
+}
+
 extern "C" {
 
 int emu_accumulate(Emu* c, int n_samples) {
@@ -184,6 +223,8 @@ int emu_accumulate(Emu* c, int n_samples) {
                 for (int u = 0; u < fp.W; u++) gris_pixel(fp, sc, P, gb, u, v, 0, 24.0f, 32, 1, c->ts);
             cd = c->color_d2.data();
             cs = c->color_s2.data();
+        } else if (getenv("VRT_EMU_POOL")) {
+            render_all_pool(c, fp, sc, out);
         } else {
             render_all<false>(c, fp, sc, out);
         }

@@ -13,6 +13,14 @@ pytestmark = pytest.mark.gpu
 REL_L2_TOL = 1e-4  # the tolerance north_star states for the HDR buffer
 
 
+@pytest.fixture(autouse=True, params=["pool", "fused"])
+def render_schedule(request, monkeypatch):
+    """Every test runs under both schedules of the render stage (vrt_pool.h / vrt_path.h); contexts that cannot
+    use the pooled kernel (ReSTIR) run the fused one either way."""
+    monkeypatch.setenv("VRT_RENDER", request.param)
+    return request.param
+
+
 def gpu_session(cfg):
     return NativeSession(_lib.load(), "vrt_", cfg)
 

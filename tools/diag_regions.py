@@ -8,7 +8,8 @@ import numpy as np
 from voxel_rt2_amd import host, scenes, materials, _lib
 from voxel_rt2_amd._session import NativeSession
 NAMES = {0: "path_begin", 1: "DDA loop trip", 2: "surface shading (frame, sun sample)", 10: "BSDF sample", 3: "shadow ray set-up/result",
-         9: "closest ray set-up/result", 4: "light-sample evaluation", 5: "escape / sky", 6: "path_finish", 8: "g-buffer (depth 0)"}
+         9: "closest ray set-up/result", 11: "pool SHADE stage", 12: "pool ESCAPE stage", 13: "pool BEGIN stage",
+         14: "pool WALK stage", 15: "pool WALK refill", 16: "pool WALK hand-over", 17: "pool WALK suspend", 4: "light-sample evaluation", 5: "escape / sky", 6: "path_finish", 8: "g-buffer (depth 0)"}
 lib = _lib.load()
 lib.vrt_diag_regions.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 for scene in sys.argv[1:] or ["s1", "sunlit", "dense"]:
@@ -30,4 +31,9 @@ for scene in sys.argv[1:] or ["s1", "sunlit", "dense"]:
         ent, lanes = int(out[2 * rid]), int(out[2 * rid + 1])
         if ent:
             print(f"  {name:38s} wave entries {ent / n:8.4f}   lanes/entry {lanes / ent:5.1f}   lane-work {lanes / n:7.3f}")
+    cyc = {k: int(out[2 * (20 + k)]) for k in range(6)}
+    if sum(cyc.values()):
+        tot = sum(cyc.values())
+        print("  pool wave-cycles by stage: " + "  ".join(f"{nm} {100 * cyc[k] / tot:.1f}%" for k, nm in
+              ((0, "BEGIN"), (1, "WALK"), (2, "SHADE"), (3, "ESCAPE"), (5, "census"), (4, "start/exit"))))
     s.close()

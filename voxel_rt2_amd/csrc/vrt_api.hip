@@ -39,6 +39,8 @@ struct vrt_ctx {
     hipStream_t stream = nullptr;
     bool owns_stream = true;
     int n_cu = 0, render_blocks = 0;
+    bool pooled = false;              // render through k_render_pool (vrt_pool.h) instead of k_render
+    uint32_t* d_pool_scratch = nullptr;
     // rows
     int own0 = 0, own1 = 0;   // rows this context produces
     int buf0 = 0, buf1 = 0;   // rows held in the buffers (own + halo)
@@ -249,7 +251,7 @@ void vrt_destroy(vrt_ctx* c) {
                     c->d_sky_trans, c->d_cloud_ambient, c->d_trans_lut, c->d_cloud_tex, c->d_cbuf[0], c->d_cbuf[1], c->d_spec_planes, c->d_color_d2,
                     c->d_color_s2, c->d_gb_pos, c->d_gb_normal[0], c->d_gb_normal[1], c->d_gb_depth[0], c->d_gb_depth[1],
                     c->d_gb_mat, c->d_refl_planes, c->d_gb_refl_f, c->d_hist_d[0], c->d_hist_d[1], c->d_hist_s[0], c->d_hist_s[1],
-                    c->d_ldr, c->d_res[0], c->d_res[1], c->d_multi_d};
+                    c->d_ldr, c->d_res[0], c->d_res[1], c->d_multi_d, c->d_pool_scratch};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (c->stream && c->owns_stream) hipStreamDestroy(c->stream);
@@ -359,11 +361,26 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
     HIP_TRY(hipSetDevice(c->device));
     const bool restir = c->cfg.use_restir != 0, instr = c->instrumented;
     if (c->render_blocks == 0) {
+        // Two schedules of the same per-path code: the fused one (a lane owns a path, vrt_path.h) and the pooled one
+        // (a wave owns a pool of paths in LDS and works stage by stage, vrt_pool.h).  The pooled kernel packs pixel
+        // coordinates in 12 bits and the depth in 4 and carries no ReSTIR state, so contexts outside that use the
+        // fused one.  VRT_RENDER=fused selects the fused kernel everywhere (A/B measurements, tests).
+        bool pooled = !restir && c->cfg.width <= 4096 && c->cfg.height <= 4096 && c->cfg.max_depth <= 15;
+        if (const char* e = getenv("VRT_RENDER")) {
+            if (strcmp(e, "fused") == 0) pooled = false;
+            else if (strcmp(e, "pool") != 0) return fail(VRT_E_INVALID, "VRT_RENDER must be 'fused' or 'pool'");
+        }
         int per_cu = 0;
-        HIP_TRY(query_render_residency(restir, instr, &per_cu));
+        if (pooled) HIP_TRY(query_render_pool_residency(instr, &per_cu));
+        else HIP_TRY(query_render_residency(restir, instr, &per_cu));
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
         c->render_blocks = per_cu * c->n_cu;
+        c->pooled = pooled;
+        if (pooled) {
+            if (c->d_pool_scratch) { HIP_TRY(hipFree(c->d_pool_scratch)); c->d_pool_scratch = nullptr; }
+            HIP_TRY(hipMalloc((void**)&c->d_pool_scratch, pool_scratch_bytes(c->render_blocks)));
+        }
     }
     // The samples of one call share camera, jitter and scene; with a still camera at full render scale and ReSTIR
     // off they only differ in their random streams, so up to VRT_MAX_FUSED of them go through ONE k_render launch
@@ -396,7 +413,8 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         hipEvent_t a, b;
         if (record(c, 0, &a, &b) != VRT_OK) return VRT_E_DEVICE;
         HIP_TRY(hipEventRecord(a, c->stream));
-        HIP_TRY(launch_render(c->stream, restir, instr, c->render_blocks, fp, sc, out, c->d_work, c->launch_seq++, g));
+        if (c->pooled) HIP_TRY(launch_render_pool(c->stream, instr, c->render_blocks, fp, sc, out, c->d_work, c->launch_seq++, g, c->d_pool_scratch));
+        else HIP_TRY(launch_render(c->stream, restir, instr, c->render_blocks, fp, sc, out, c->d_work, c->launch_seq++, g));
         HIP_TRY(hipEventRecord(b, c->stream));
         const f3* cd = out.color_d;
         const f3* cs = out.color_s;

@@ -8,12 +8,18 @@
 #include "vrt_bsdf.h"
 #include "vrt_sky.h"
 #include "vrt_path.h"
+#include "vrt_pool.h"
 #include "vrt_restir.h"
 #include "vrt_temporal.h"
 
 #define VRT_RENDER_THREADS 256
 #ifndef VRT_RENDER_MIN_WAVES
 #define VRT_RENDER_MIN_WAVES 2   // waves per SIMD the register allocator must leave room for (tuned on MI355X)
+#endif
+
+#define VRT_POOL_WAVES 4           // waves (= path pools) per workgroup of the pooled render kernel
+#ifndef VRT_POOL_MIN_WAVES
+#define VRT_POOL_MIN_WAVES 2
 #endif
 
 namespace vrt {
@@ -23,6 +29,11 @@ hipError_t launch_prepare(hipStream_t st, const int8_t* mat, const uint8_t* rgb,
 hipError_t query_render_residency(bool restir, bool instr, int* blocks_per_cu);
 hipError_t launch_render(hipStream_t st, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                          const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples);
+// pooled schedule (vrt_pool.h), ReSTIR off only.  `cold` holds pool_scratch_bytes(n_blocks) bytes.
+hipError_t query_render_pool_residency(bool instr, int* blocks_per_cu);
+size_t pool_scratch_bytes(int n_blocks);
+hipError_t launch_render_pool(hipStream_t st, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
+                              const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold);
 hipError_t launch_gris(hipStream_t st, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1);
 hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1, int n_samples);
 hipError_t launch_tonemap(hipStream_t st, const FrameParams& fp, const f3* hdr, f4* ldr, int r0, int r1);

@@ -159,6 +159,196 @@ __global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_re
     if (INSTR) flush_stats(ts, sc.counters);
 }
 
+// ---- render, pooled schedule (vrt_pool.h) ------------------------------------------------------
+// One wave = one pool of VRT_POOL_SLOTS path records in LDS.  Everything below the stage functions is wave-uniform
+// bookkeeping: a census of slot states (ballots), a compacted list of the slots the chosen stage will work on, and
+// the WALK loop's in-loop refill.  Waves never talk to each other; the only workgroup-level object is the staged
+// pyramid / material table.  The wave leaves when the work counter is exhausted and its pool has drained.
+#ifndef VRT_POOL_REFILL
+#define VRT_POOL_REFILL 16   // WALK: idle lanes that trigger a refill from the pending list
+#endif
+#ifndef VRT_POOL_PARK
+#define VRT_POOL_PARK 16     // WALK: with the list empty, suspend the walks still going once this few are left
+#endif
+#define VRT_POOL_WORDS (VRT_POOL_SLOTS / 64)
+
+__device__ __forceinline__ void wave_lds_sync() {  // LDS written by some lanes of this wave, read by others
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+template <bool INSTR>
+__global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_render_pool(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold) {
+    __shared__ unsigned long long s_l1[512];
+    __shared__ unsigned long long s_l2[8];
+    __shared__ float s_mats[128 * 14];
+    __shared__ uint32_t s_pool[VRT_POOL_WAVES][PF_COUNT * VRT_POOL_SLOTS];
+    __shared__ uint32_t s_state[VRT_POOL_WAVES][VRT_POOL_SLOTS];
+    __shared__ uint32_t s_list[VRT_POOL_WAVES][VRT_POOL_SLOTS];
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
+    if (threadIdx.x < 8) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
+    for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *next_counter = 0u;  // the next launch's counter (idle during this launch)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* const pool = s_pool[wave];
+    uint32_t* const state = s_state[wave];
+    uint32_t* const list = s_list[wave];
+    for (int k = 0; k < VRT_POOL_WORDS; k++) state[k * 64 + lane] = SLOT_EMPTY;
+    __syncthreads();
+    LdsPyramid P;
+    P.l0 = sc.pyr.l0; P.l1 = s_l1; P.l2 = s_l2;
+    SceneData scl = sc;
+    scl.mats = s_mats;
+    uint32_t* const cold_wave = cold + (size_t)(blockIdx.x * VRT_POOL_WAVES + wave) * VRT_POOL_SLOTS * PC_COUNT;
+
+    const int tiles_x = (fp.W + 7) >> 3;
+    const int tiles_y = (fp.row1 - fp.row0 + 7) >> 3;
+    const unsigned total = (unsigned)(tiles_x * tiles_y) * 64u * (unsigned)n_samples;  // (tile, sample, pixel-in-tile) items
+    TraceStats ts;
+    stats_zero(ts);
+    bool exhausted = false;  // wave-uniform
+
+#if defined(VRT_DIAG_REGIONS)
+    unsigned long long t_prev = __builtin_readcyclecounter();
+    int prev_stage = 4;  // 4 = start-up
+#define VRT_POOL_CLOCK(next_stage)                                                                              \
+    do {                                                                                                        \
+        const unsigned long long t_now = __builtin_readcyclecounter();                                          \
+        if (lane == 0) atomicAdd(&g_vrt_region[2 * (20 + prev_stage)], t_now - t_prev);                         \
+        t_prev = t_now; prev_stage = (next_stage);                                                              \
+    } while (0)
+#else
+#define VRT_POOL_CLOCK(next_stage) ((void)0)
+#endif
+    for (;;) {
+        wave_lds_sync();
+        VRT_POOL_CLOCK(5);  // 5 = census + list
+        // census
+        uint32_t st[VRT_POOL_WORDS];
+        int cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < VRT_POOL_WORDS; k++) {
+            st[k] = state[k * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < 4; q++) cnt[q] += __popcll(__ballot(st[k] == (uint32_t)q));
+        }
+        if (exhausted) cnt[SLOT_EMPTY] = 0;
+        // the stage with the most slots waiting; ties: SHADE, ESCAPE, WALK, BEGIN
+        int stage = SLOT_SHADE, best = cnt[SLOT_SHADE];
+        if (cnt[SLOT_ESCAPE] > best) { stage = SLOT_ESCAPE; best = cnt[SLOT_ESCAPE]; }
+        if (cnt[SLOT_RAY] > best) { stage = SLOT_RAY; best = cnt[SLOT_RAY]; }
+        if (cnt[SLOT_EMPTY] > best) { stage = SLOT_EMPTY; best = cnt[SLOT_EMPTY]; }
+        if (best == 0) break;  // nothing pending and no work left
+        // compacted list of that stage's slots
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < VRT_POOL_WORDS; k++) {
+            const bool mine = st[k] == (uint32_t)stage;
+            const unsigned long long m = __ballot(mine);
+            if (mine) list[n + lane_rank(m)] = (uint32_t)(k * 64 + lane);
+            n += __popcll(m);
+        }
+        wave_lds_sync();
+        VRT_POOL_CLOCK(stage);
+
+        if (stage == SLOT_RAY) {
+            VRT_REGION(14);
+            const int park = (n >= 64) ? VRT_POOL_PARK : 0;  // suspending only pays when other stages then have work
+            int head = 0;
+            bool active = false, ended = false;
+            RayWalk w;
+            BrickCache bc;
+            bc.key = -1; bc.word = 0ULL;
+            SlotRef s;
+            s.base = pool; s.stride = VRT_POOL_SLOTS;
+            int slot = 0, iters0 = 0;
+            for (;;) {
+                // event: finished walks go to their slots, idle lanes take the next pending rays -- or, with the
+                // list empty and few walks left, the rest is suspended
+                const unsigned long long idle = __ballot(!active);
+                const int n_idle = __popcll(idle);
+                if (ended) {
+                    VRT_REGION(16);
+                    walk_store(s, w);
+                    state[slot] = (uint32_t)slot_state_after_walk(w.t, s.f(PF_FLOOR_T));
+                    ts.iters += (unsigned)(w.iters - iters0);
+                    ended = false;
+                }
+                if (head >= n) {
+                    if (64 - n_idle <= park) {
+                        if (active) {  // suspend: the slot stays SLOT_RAY
+                            VRT_REGION(17);
+                            walk_store(s, w);
+                            ts.iters += (unsigned)(w.iters - iters0);
+                        }
+                        break;
+                    }
+                } else {
+                    const int idx = head + lane_rank(idle);
+                    if (!active && idx < n) {
+                        VRT_REGION(15);
+                        slot = (int)list[idx];
+                        s.base = pool + slot;
+                        walk_load(s, w);
+                        bc.key = -1;
+                        iters0 = w.iters;
+                        active = true;
+                    }
+                    head += (n_idle < n - head) ? n_idle : n - head;
+                }
+                // the DDA loop proper: nothing but steps until enough lanes have gone idle for the next event
+                const int target = (head < n) ? VRT_POOL_REFILL : 64 - park;
+                do {
+                    if (active) {
+                        int nq;
+                        if (walk_trip(P, w, bc, nq)) { active = false; ended = true; }
+                        ts.queries += (unsigned)nq;
+                    }
+                } while (__popcll(__ballot(!active)) < target);
+            }
+        } else {
+            const int take = n < 64 ? n : 64;
+            unsigned base = 0u;
+            if (stage == SLOT_EMPTY) {
+                if (lane == 0) base = atomicAdd(work_counter, (unsigned)take);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if (base + (unsigned)take >= total) exhausted = true;
+            }
+            if (lane < take) {
+                const int slot = (int)list[lane];
+                SlotRef s;
+                s.base = pool + slot; s.stride = VRT_POOL_SLOTS;
+                uint32_t* const cold_line = cold_wave + slot * PC_COUNT;
+                if (stage == SLOT_SHADE) {
+                    VRT_REGION(11);
+                    state[slot] = (uint32_t)pool_shade<HIT_SOMETHING>(fp, scl, P, out, s, cold_line, ts);
+                } else if (stage == SLOT_ESCAPE) {
+                    VRT_REGION(12);
+                    state[slot] = (uint32_t)pool_shade<HIT_NOTHING>(fp, scl, P, out, s, cold_line, ts);
+                } else {
+                    VRT_REGION(13);
+                    const unsigned my = base + (unsigned)lane;
+                    if (my < total) {
+                        const unsigned group = my >> 6, in = my & 63u;
+                        const unsigned tile = group / (unsigned)n_samples;
+                        const int sample = (int)(group % (unsigned)n_samples);
+                        const int u = (int)(tile % (unsigned)tiles_x) * 8 + (int)(in & 7u);
+                        const int v = fp.row0 + (int)(tile / (unsigned)tiles_x) * 8 + (int)(in >> 3);
+                        if (u < fp.W && v < fp.row1 && !outside_render_area(fp, (float)u, (float)v))
+                            state[slot] = (uint32_t)pool_begin(fp, s, u, v, sample, ts);
+                    }
+                }
+            }
+        }
+    }
+    VRT_POOL_CLOCK(4);
+    if (INSTR) flush_stats(ts, sc.counters);
+}
+
 // ---- spatial reuse ---------------------------------------------------------------------------
 template <bool INSTR>
 #ifndef VRT_GRIS_MIN_WAVES
@@ -275,6 +465,21 @@ hipError_t launch_render(hipStream_t st, bool restir, bool instr, int n_blocks, 
         if (instr) hipLaunchKernelGGL((k_render<false, true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk, n_samples);
         else hipLaunchKernelGGL((k_render<false, false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk, n_samples);
     }
+    VRT_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t query_render_pool_residency(bool instr, int* blocks_per_cu) {
+    return instr ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool<true>, 64 * VRT_POOL_WAVES, 0)
+                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool<false>, 64 * VRT_POOL_WAVES, 0);
+}
+size_t pool_scratch_bytes(int n_blocks) { return (size_t)n_blocks * VRT_POOL_WAVES * VRT_POOL_SLOTS * PC_COUNT * sizeof(uint32_t); }
+hipError_t launch_render_pool(hipStream_t st, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
+                              const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold) {
+    unsigned* work_counter = work_counters + (launch_seq & 1u);
+    unsigned* next_counter = work_counters + ((launch_seq + 1u) & 1u);
+    dim3 g(n_blocks), b(64 * VRT_POOL_WAVES);
+    if (instr) hipLaunchKernelGGL((k_render_pool<true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold);
+    else hipLaunchKernelGGL((k_render_pool<false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold);
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }

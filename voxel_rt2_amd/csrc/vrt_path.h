@@ -178,15 +178,17 @@ VRT_DEV void path_begin(const FrameParams& fp, Path<RESTIR>& p, int u, int v, in
     }
 }
 
-// Advance one segment (one iteration of pathtracer.py:396-525).  Returns true when the path is over.
-template <bool RESTIR, class PyrT>
-VRT_DEV bool path_segment(const FrameParams& fp, const SceneData& sc, const PyrT& P, const PixelBuffers& out, int local_idx,
-                          Path<RESTIR>& p, TraceStats& ts) {
+// What the caller already knows about the hit handed to path_shade(): lets a stage that only ever sees one kind
+// (vrt_pool.h) drop the other kind's code.
+enum { HIT_ANY = 0, HIT_SOMETHING = 1, HIT_NOTHING = 2 };
+
+// One iteration of pathtracer.py:396-525 after its closest-hit query `h`.  Returns true when the path is over.
+template <bool RESTIR, int KIND, class PyrT>
+VRT_DEV bool path_shade(const FrameParams& fp, const SceneData& sc, const PyrT& P, const PixelBuffers& out, int local_idx,
+                        Path<RESTIR>& p, const Hit& h, TraceStats& ts) {
     const int depth = p.depth;
-    Hit h;
-    next_hit<false>(fp, sc, P, p.pos, p.d, h, ts);
     const f3 hit_pos = p.pos + h.closest * p.d;
-    const bool surface = (!h.hit_light) && (h.closest < DM_INF);
+    const bool surface = (KIND != HIT_NOTHING) && (!h.hit_light) && (h.closest < DM_INF);
 
     if (depth == 0) {
         VRT_REGION(8);
@@ -300,7 +302,7 @@ VRT_DEV bool path_segment(const FrameParams& fp, const SceneData& sc, const PyrT
         return p.depth >= fp.max_depth;
     }
 
-    if (h.closest == DM_INF) {
+    if (KIND != HIT_SOMETHING && h.closest == DM_INF) {
         VRT_REGION(5);
         // escaped: background colour or skybox, plus the sun disc (pathtracer.py:500-517)
         const float hit_sun = (dot3(fp.light_dir, p.d) >= fp.light_cos_max) ? 1.0f : 0.0f;
@@ -318,6 +320,15 @@ VRT_DEV bool path_segment(const FrameParams& fp, const SceneData& sc, const PyrT
         if constexpr (RESTIR) { if (depth >= 2) p.rs.rc_incident_L = p.rs.rc_incident_L + firefly(p.rs.thr_after_rc * h.albedo); }
     }
     return true;
+}
+
+// Advance one segment: closest-hit query, then path_shade().
+template <bool RESTIR, class PyrT>
+VRT_DEV bool path_segment(const FrameParams& fp, const SceneData& sc, const PyrT& P, const PixelBuffers& out, int local_idx,
+                          Path<RESTIR>& p, TraceStats& ts) {
+    Hit h;
+    next_hit<false>(fp, sc, P, p.pos, p.d, h, ts);
+    return path_shade<RESTIR, HIT_ANY>(fp, sc, P, out, local_idx, p, h, ts);
 }
 
 // defined in vrt_restir.h: builds the input reservoir (pathtracer.py:549-607, 620-626)

@@ -1,0 +1,214 @@
+// vrt_pool.h -- camera paths as records in a per-wave LDS pool, advanced stage by stage.
+//
+// Same arithmetic as vrt_path.h (Renderer.render, reference renderer/pathtracer.py:355-632), different schedule.
+// In the fused kernel (k_render) a lane owns one path and walks it segment by segment; a wave of 64 rays then
+// runs its DDA loop until the LONGEST of them is done (measured: 25 of 64 lanes busy in that loop on the sparse
+// scene, 16 on the dense one) and shades hits, misses and fresh pixels side by side in one divergent pass.
+//
+// Here a wave owns VRT_POOL_SLOTS (> 64) paths.  Their state lives in LDS, not in lanes, so that the wave can pick
+// what to do next by what there is most of:
+//
+//   WALK    the DDA loop over every pending ray.  A lane whose ray ends hands the result to the ray's slot and
+//           takes the next pending ray IN the loop, so the loop runs full until the list is empty; the few rays
+//           still going when too few lanes are left are suspended back into their slots (RayWalk is resumable).
+//   SHADE   64 paths whose ray found a surface: path_shade<HIT_SOMETHING>, then the set-up of the bounce ray.
+//   ESCAPE  64 paths whose ray left the scene: sky / background, path_finish.
+//   BEGIN   64 empty slots: fresh (tile, sample, pixel) work items, path_begin, set-up of the camera ray.
+//
+// Each stage therefore runs one piece of code on (nearly) 64 lanes.  Results do not depend on the schedule: a
+// path owns its random stream and its output pixel, and every stage function is the fused path's code
+// (walk_prepare/walk_trip = raytrace(); path_shade = the rest of path_segment()).
+//
+// The record is split by how often it is touched: 25 dwords that every stage needs stay in LDS (SoA, one
+// column per slot); 14 dwords written at the primary vertex and read back only by path_finish (light-sample sums,
+// primary vertex data) go to a per-wave scratch line in global memory, which stays in L2.
+#ifndef VRT_POOL_H
+#define VRT_POOL_H
+
+#include "vrt_path.h"
+
+#ifndef VRT_POOL_SLOTS
+#define VRT_POOL_SLOTS 128
+#endif
+
+namespace vrt {
+
+enum {  // slot states
+    SLOT_EMPTY = 0,   // no path: BEGIN may use it
+    SLOT_RAY = 1,     // closest-hit ray pending or suspended
+    SLOT_SHADE = 2,   // ray ended on the floor or a voxel
+    SLOT_ESCAPE = 3   // ray ended on nothing
+};
+
+enum {  // LDS columns of a slot (dwords)
+    PF_POS = 0, PF_DIR = 3, PF_THR = 6, PF_CONTRIB = 9, PF_RNG = 12,
+    PF_IDS = 13,      // pix_u | pix_v << 12 | depth << 24 | sample << 28
+    PF_FLAGS = 14,    // first_lobe | sky_primary << 2
+    PF_REFL = 15,
+    PF_FLOOR_T = 16,  // floor_probe() of the pending ray
+    PF_T = 17,        // RayWalk.t: distance so far / final distance
+    PF_FAR = 18,
+    PF_INV = 19,      // RayWalk.inv_dir
+    PF_CELL_XY = 22,  // ix | iy << 16 (two's complement halves)
+    PF_CELL_Z = 23,   // iz | lod << 16 | normal code << 20
+    PF_ITERS = 24,
+    PF_COUNT = 25
+};
+enum { PC_NEE_D = 0, PC_NEE_S = 3, PC_ALBEDO = 6, PC_PPOS = 9, PC_INVPDF = 12, PC_MAT = 13, PC_COUNT = 16 };  // scratch line
+
+// A slot's column in the pool: field f lives at base[f * stride].
+struct SlotRef {
+    uint32_t* base;
+    int stride;
+    VRT_DEV uint32_t u(int f) const { return base[f * stride]; }
+    VRT_DEV float f(int f_) const { return dm_u2f(base[f_ * stride]); }
+    VRT_DEV f3 v(int f_) const { return mk3(f(f_), f(f_ + 1), f(f_ + 2)); }
+    VRT_DEV void su(int f_, uint32_t x) const { base[f_ * stride] = x; }
+    VRT_DEV void sf(int f_, float x) const { base[f_ * stride] = dm_f2u(x); }
+    VRT_DEV void sv(int f_, f3 x) const { sf(f_, x.x); sf(f_ + 1, x.y); sf(f_ + 2, x.z); }
+};
+
+// the step normal has components in {+0, -0, +1, -1}: two bits each (sign, magnitude)
+VRT_DEV uint32_t normal_code(f3 n) {
+    const uint32_t cx = (dm_f2u(n.x) >> 31) | (n.x != 0.0f ? 2u : 0u);
+    const uint32_t cy = (dm_f2u(n.y) >> 31) | (n.y != 0.0f ? 2u : 0u);
+    const uint32_t cz = (dm_f2u(n.z) >> 31) | (n.z != 0.0f ? 2u : 0u);
+    return cx | (cy << 2) | (cz << 4);
+}
+VRT_DEV float normal_comp(uint32_t c) { return dm_u2f(((c & 1u) << 31) | ((c & 2u) ? 0x3f800000u : 0u)); }
+VRT_DEV f3 normal_decode(uint32_t c) { return mk3(normal_comp(c), normal_comp(c >> 2), normal_comp(c >> 4)); }
+
+VRT_DEV void walk_store(const SlotRef& s, const RayWalk& w) {
+    s.sf(PF_T, w.t);
+    s.su(PF_CELL_XY, ((uint32_t)w.ix & 0xffffu) | ((uint32_t)w.iy << 16));
+    s.su(PF_CELL_Z, ((uint32_t)w.iz & 0xffffu) | ((uint32_t)w.lod << 16) | (normal_code(w.hn) << 20));
+    s.su(PF_ITERS, (uint32_t)w.iters);
+}
+VRT_DEV void walk_store_constants(const SlotRef& s, const RayWalk& w) {
+    s.sf(PF_FAR, w.far);
+    s.sv(PF_INV, w.inv_dir);
+}
+VRT_DEV void walk_load(const SlotRef& s, RayWalk& w) {
+    w.o = world_to_voxel(s.v(PF_POS));
+    w.d = s.v(PF_DIR);
+    w.sd = mk3(sgn(w.d.x), sgn(w.d.y), sgn(w.d.z));
+    w.inv_dir = s.v(PF_INV);
+    w.t = s.f(PF_T);
+    w.far = s.f(PF_FAR);
+    const uint32_t a = s.u(PF_CELL_XY), b = s.u(PF_CELL_Z);
+    w.ix = (int)(int16_t)(a & 0xffffu); w.iy = (int)(int16_t)(a >> 16); w.iz = (int)(int16_t)(b & 0xffffu);
+    w.lod = (int)((b >> 16) & 7u);
+    w.hn = normal_decode(b >> 20);
+    w.iters = (int)s.u(PF_ITERS);
+}
+
+VRT_DEV uint32_t pack_ids(int u, int v, int depth, int sample) {
+    return (uint32_t)u | ((uint32_t)v << 12) | ((uint32_t)depth << 24) | ((uint32_t)sample << 28);
+}
+
+template <bool RESTIR>
+VRT_DEV void path_store_hot(const SlotRef& s, const Path<RESTIR>& p) {
+    s.sv(PF_POS, p.pos); s.sv(PF_DIR, p.d); s.sv(PF_THR, p.thr); s.sv(PF_CONTRIB, p.contrib);
+    s.su(PF_RNG, p.rng.s);
+    s.su(PF_IDS, pack_ids(p.pix_u, p.pix_v, p.depth, p.sample));
+    s.su(PF_FLAGS, (uint32_t)p.first_lobe | ((uint32_t)p.sky_primary << 2));
+    s.sf(PF_REFL, p.refl_dist);
+}
+// the fields a path leaves its primary vertex with (path_begin's defaults until then)
+template <bool RESTIR>
+VRT_DEV void path_cold_defaults(Path<RESTIR>& p) {
+    p.nee_d = mk3(0.0f); p.nee_s = mk3(0.0f);
+    p.primary_albedo = mk3(1.0f); p.primary_pos = mk3(0.0f);
+    p.first_invpdf = 1.0f;
+    p.primary_mat_info = 0u;
+}
+template <bool RESTIR>
+VRT_DEV void path_load_hot(const SlotRef& s, Path<RESTIR>& p) {
+    p.pos = s.v(PF_POS); p.d = s.v(PF_DIR); p.thr = s.v(PF_THR); p.contrib = s.v(PF_CONTRIB);
+    p.rng.s = s.u(PF_RNG);
+    const uint32_t ids = s.u(PF_IDS), fl = s.u(PF_FLAGS);
+    p.pix_u = (int)(ids & 0xfffu); p.pix_v = (int)((ids >> 12) & 0xfffu);
+    p.depth = (int)((ids >> 24) & 15u); p.sample = (int)(ids >> 28);
+    p.first_lobe = (int)(fl & 3u); p.sky_primary = (int)((fl >> 2) & 1u);
+    p.refl_dist = s.f(PF_REFL);
+    path_cold_defaults(p);
+}
+template <bool RESTIR>
+VRT_DEV void path_store_cold(uint32_t* line, const Path<RESTIR>& p) {
+    line[PC_NEE_D] = dm_f2u(p.nee_d.x); line[PC_NEE_D + 1] = dm_f2u(p.nee_d.y); line[PC_NEE_D + 2] = dm_f2u(p.nee_d.z);
+    line[PC_NEE_S] = dm_f2u(p.nee_s.x); line[PC_NEE_S + 1] = dm_f2u(p.nee_s.y); line[PC_NEE_S + 2] = dm_f2u(p.nee_s.z);
+    line[PC_ALBEDO] = dm_f2u(p.primary_albedo.x); line[PC_ALBEDO + 1] = dm_f2u(p.primary_albedo.y); line[PC_ALBEDO + 2] = dm_f2u(p.primary_albedo.z);
+    line[PC_PPOS] = dm_f2u(p.primary_pos.x); line[PC_PPOS + 1] = dm_f2u(p.primary_pos.y); line[PC_PPOS + 2] = dm_f2u(p.primary_pos.z);
+    line[PC_INVPDF] = dm_f2u(p.first_invpdf);
+    line[PC_MAT] = p.primary_mat_info;
+}
+template <bool RESTIR>
+VRT_DEV void path_load_cold(const uint32_t* line, Path<RESTIR>& p) {
+    p.nee_d = mk3(dm_u2f(line[PC_NEE_D]), dm_u2f(line[PC_NEE_D + 1]), dm_u2f(line[PC_NEE_D + 2]));
+    p.nee_s = mk3(dm_u2f(line[PC_NEE_S]), dm_u2f(line[PC_NEE_S + 1]), dm_u2f(line[PC_NEE_S + 2]));
+    p.primary_albedo = mk3(dm_u2f(line[PC_ALBEDO]), dm_u2f(line[PC_ALBEDO + 1]), dm_u2f(line[PC_ALBEDO + 2]));
+    p.primary_pos = mk3(dm_u2f(line[PC_PPOS]), dm_u2f(line[PC_PPOS + 1]), dm_u2f(line[PC_PPOS + 2]));
+    p.first_invpdf = dm_u2f(line[PC_INVPDF]);
+    p.primary_mat_info = line[PC_MAT];
+}
+
+// What becomes of a closest-hit ray that ended at distance t (voxel units) given the floor distance of its path
+// (the comparison of hit_voxel(), pathtracer.py:203-204).
+VRT_DEV int slot_state_after_walk(float t, float floor_t) {
+    return (t * (1.0f / 64.0f) < floor_t || floor_t < DM_INF) ? SLOT_SHADE : SLOT_ESCAPE;
+}
+
+// Set up the closest-hit ray of the path in `s` (its pos and dir are stored already): floor distance and the
+// prepared walk.  A ray that misses the grid box has nothing to walk and goes straight to SHADE / ESCAPE.
+VRT_DEV int pool_launch_ray(const FrameParams& fp, const SlotRef& s, f3 pos, f3 d, TraceStats& ts) {
+    const float ft = floor_probe(fp, pos, d);
+    s.sf(PF_FLOOR_T, ft);
+    RayWalk w;
+    const bool alive = walk_prepare(world_to_voxel(pos), d, w);
+    ts.rays += 1u;
+    walk_store(s, w);
+    walk_store_constants(s, w);
+    return alive ? SLOT_RAY : slot_state_after_walk(w.t, ft);
+}
+
+// BEGIN: work item (u, v, sample) -> camera ray pending.
+VRT_DEV int pool_begin(const FrameParams& fp, const SlotRef& s, int u, int v, int sample, TraceStats& ts) {
+    Path<false> p;
+    path_begin(fp, p, u, v, sample);
+    path_store_hot(s, p);
+    return pool_launch_ray(fp, s, p.pos, p.d, ts);
+}
+
+// SHADE (KIND = HIT_SOMETHING) and ESCAPE (KIND = HIT_NOTHING): rebuild the closest hit from the slot, run the
+// segment, then either set up the bounce ray or finish the path.  Returns the slot's next state.
+template <int KIND, class PyrT>
+VRT_DEV int pool_shade(const FrameParams& fp, const SceneData& sc, const PyrT& P, const PixelBuffers& out, const SlotRef& s,
+                       uint32_t* cold_line, TraceStats& ts) {
+    Path<false> p;
+    path_load_hot(s, p);
+    const int local_idx = (p.pix_v - fp.row0) * fp.W + p.pix_u;
+    const int depth = p.depth;
+    Hit h;
+    hit_init(h);
+    if (KIND == HIT_SOMETHING) {
+        const float ft = s.f(PF_FLOOR_T);
+        if (ft < DM_INF) hit_floor(fp, p.d, ft, h);
+        const uint32_t a = s.u(PF_CELL_XY), b = s.u(PF_CELL_Z);
+        TraceOut tr;
+        walk_result(p.d, s.f(PF_T), (int)(int16_t)(a & 0xffffu), (int)(int16_t)(a >> 16), (int)(int16_t)(b & 0xffffu),
+                    normal_decode(b >> 20), (int)s.u(PF_ITERS), tr);
+        hit_voxel<false>(fp, sc, world_to_voxel(p.pos), p.d, tr, h, ts);
+    }
+    const bool done = path_shade<false, KIND>(fp, sc, P, out, local_idx, p, h, ts);
+    if (done) {
+        if (depth > 0) path_load_cold(cold_line, p);
+        path_finish<false>(fp, sc, out, local_idx, p, ts);
+        return SLOT_EMPTY;
+    }
+    if (depth == 0) path_store_cold(cold_line, p);
+    path_store_hot(s, p);
+    return pool_launch_ray(fp, s, p.pos, p.d, ts);
+}
+
+}  // namespace vrt
+#endif

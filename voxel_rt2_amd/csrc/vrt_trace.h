@@ -65,6 +65,45 @@ VRT_DEV int descend(const PyrT& P, int x, int y, int z, int lod, bool& solid, Br
     return 0;
 }
 
+// One 4x4x4 brick word answers two LODs for the cell (cx,cy,cz) of its finer level: bit 0 of the result = that
+// cell is occupied, bit 1 = the 2x2x2 block around it holds an occupied cell.  The z&2 half of the word is picked
+// first so that everything after it is 32-bit work (the 0x00330033 block mask shifted by at most 10 still fits).
+VRT_DEV unsigned brick_two_lods(unsigned long long w, int cx, int cy, int cz) {
+    const unsigned half = (cz & 2) ? (unsigned)(w >> 32) : (unsigned)w;
+    const unsigned cell = (half >> (((cz & 1) << 4) | ((cy & 3) << 2) | (cx & 3))) & 1u;
+    const unsigned block = (half & (0x00330033u << (((cy & 2) << 2) | (cx & 2)))) != 0u ? 2u : 0u;
+    return block | cell;
+}
+
+// descend() without the walk: same result, fixed cost.  descend() is a seven-way nest of branches; a wave whose
+// lanes sit at mixed LODs executes most of it (about 190 of the 256 instructions of a DDA step), which is what a
+// FULL wave of rays does -- the pooled schedule's WALK stage (vrt_pool.h).  Here the occupancy of all seven levels
+// of the cell is gathered into one 7-bit mask -- two LDS words and the cached fine brick word -- and the level the
+// walk stops at is the highest empty level at or below the starting one: a complement, a mask, a count-leading-
+// zeros.  (A wave with few active lanes, whose rays mostly stop at their first query, is better off with descend():
+// measured 3-10 % on the fused kernel.)
+template <class PyrT>
+VRT_DEV int descend_flat(const PyrT& P, int x, int y, int z, int lod, bool& solid, BrickCache& bc, int& nq) {
+    const bool inside = ((x | y | z) & ~(VRT_GRID - 1)) == 0;  // outside the grid: empty, as in descend()
+    const int xm = x & (VRT_GRID - 1), ym = y & (VRT_GRID - 1), zm = z & (VRT_GRID - 1);  // keeps the table indices in range
+    const unsigned long long w2 = P.load_l2((((zm >> 6) << 1) | (ym >> 6)) << 1 | (xm >> 6));
+    const unsigned long long w1 = P.load_l1((((zm >> 4) << 3) | (ym >> 4)) << 3 | (xm >> 4));
+    unsigned occ = (w2 != 0ULL ? 64u : 0u) | (brick_two_lods(w2, xm >> 4, ym >> 4, zm >> 4) << 4) |
+                   (brick_two_lods(w1, xm >> 2, ym >> 2, zm >> 2) << 2);
+    const unsigned upto = (2u << lod) - 1u;  // levels 0..lod
+    // the fine brick word matters only when every level from `lod` down to 2 is occupied
+    if (inside && (~occ & upto & ~3u) == 0u) {
+        const int key = (((zm >> 2) << 5) | (ym >> 2)) << 5 | (xm >> 2);
+        if (key != bc.key) { bc.key = key; bc.word = P.load_l0(key); }
+        occ |= brick_two_lods(bc.word, xm, ym, zm);
+    }
+    const unsigned empty = inside ? (~occ & upto) : upto;
+    solid = empty == 0u;
+    const int level = solid ? 0 : 31 - __builtin_clz(empty);
+    nq = lod - level + 1;
+    return level;
+}
+
 struct GlobalPyramid {  // all three brick levels read from global memory
     Pyramid p;
     VRT_DEV unsigned long long load_l0(int i) const { return p.l0[i]; }
@@ -146,43 +185,128 @@ VRT_DEV void raytrace(const PyrT& P, f3 o, f3 d, TraceOut& r, int& queries) {
     r.iters = iters;
 }
 
+// ---- the same walk as a resumable record ---------------------------------------------------------
+// RayWalk holds exactly the loop-carried state of raytrace() above, so a walk can be set up by one piece of code,
+// advanced a step at a time by another and suspended in between (vrt_pool.h keeps suspended walks in LDS).
+// walk_prepare + walk_trip until it returns true + walk_result compute what raytrace() computes, bit for bit.
+struct RayWalk {
+    f3 o, d, inv_dir, sd;  // sd = sign(d), a function of d kept beside it
+    float t, far;          // hit_distance, exit distance of the grid box
+    int ix, iy, iz, lod, iters;
+    f3 hn;
+};
+
+// raytracer.py:81-101: clip against the grid box, first cell, entry-face normal.  False = the box is missed.
+VRT_DEV bool walk_prepare(f3 o, f3 d, RayWalk& w) {
+    w.o = o; w.d = d;
+    w.sd = mk3(sgn(d.x), sgn(d.y), sgn(d.z));
+    w.t = DM_INF; w.far = 0.0f;
+    w.ix = -1; w.iy = -1; w.iz = -1; w.lod = 0; w.iters = 0;
+    w.hn = mk3(0.0f);
+    w.inv_dir = mk3(0.0f);
+    const float res = (float)VRT_GRID;
+    float near_t = -DM_INF, far_t = DM_INF;
+#define VRT_SLAB(oc, dc)                                                     \
+    if (dc != 0.0f) {                                                        \
+        float i1 = (0.0f - oc) / dc, i2 = (res - oc) / dc;                   \
+        far_t = dm_min(dm_max(i1, i2), far_t);                               \
+        near_t = dm_max(dm_min(i1, i2), near_t);                             \
+    }
+    VRT_SLAB(o.x, d.x) VRT_SLAB(o.y, d.y) VRT_SLAB(o.z, d.z)
+#undef VRT_SLAB
+    if (!(near_t <= far_t && VRT_EPS < far_t && DM_INF > near_t)) return false;
+    w.t = dm_max(near_t, VRT_EPS);
+    const f3 p0 = o + d * (w.t + VRT_EPS);
+    const f3 c = clamp3(floor3(p0), 0.0f, res - 1.0f);
+    w.ix = (int)c.x; w.iy = (int)c.y; w.iz = (int)c.z;
+    w.inv_dir = mk3(1.0f / dm_abs(d.x), 1.0f / dm_abs(d.y), 1.0f / dm_abs(d.z));
+    w.far = dm_min(DM_INF, far_t) - VRT_EPS;
+    const f3 id = abs3(p0 - res * 0.5f);
+    const float md = dm_max(dm_max(id.x, id.y), id.z);
+    w.hn = mk3(md == id.x ? 1.0f : 0.0f, md == id.y ? 1.0f : 0.0f, md == id.z ? 1.0f : 0.0f);
+    return true;
+}
+
+// One pass of the loop raytracer.py:103-147.  True = the walk is over (hit, miss or 512 steps).
+template <class PyrT>
+VRT_DEV bool walk_trip(const PyrT& P, RayWalk& w, BrickCache& bc, int& nq) {
+    nq = 0;
+    if (w.iters >= 512) return true;
+    if (w.t > w.far) { w.t = DM_INF; return true; }
+    bool solid;
+    VRT_REGION(1);
+#if defined(VRT_WALK_BRANCHY)
+    w.lod = descend(P, w.ix, w.iy, w.iz, w.lod, solid, bc, nq);
+#else
+    w.lod = descend_flat(P, w.ix, w.iy, w.iz, w.lod, solid, bc, nq);
+#endif
+    if (solid) return true;
+    const int lod = w.lod;
+    const f3 d = w.d;
+    const float cell_size = (float)(1 << lod);
+    const f3 cell_base = mk3((float)(w.ix >> lod), (float)(w.iy >> lod), (float)(w.iz >> lod)) * cell_size;
+    const f3 fp = (w.o + d * w.t) - cell_base;
+    f3 dist;
+    dist.x = (d.x > 0.0f) ? cell_size - fp.x : fp.x;
+    dist.y = (d.y > 0.0f) ? cell_size - fp.y : fp.y;
+    dist.z = (d.z > 0.0f) ? cell_size - fp.z : fp.z;
+    const f3 t = dist * w.inv_dir;
+    const float min_t = dm_min(dm_min(t.x, t.y), t.z);
+    const f3 edge = clamp3(floor3(fp + min_t * d), 0.0f, cell_size - 1.0f);
+    w.t += min_t;
+    w.hn = mk3(t.x == min_t ? 1.0f : 0.0f, t.y == min_t ? 1.0f : 0.0f, t.z == min_t ? 1.0f : 0.0f) * w.sd;
+    const f3 nxt = cell_base + edge + w.hn;
+    w.ix = (int)nxt.x; w.iy = (int)nxt.y; w.iz = (int)nxt.z;
+    w.lod = (lod + 1 > 6) ? 6 : lod + 1;
+    w.iters += 1;
+    return false;
+}
+
+// raytracer.py:152-155
+VRT_DEV void walk_result(f3 d, float t, int ix, int iy, int iz, f3 hn, int iters, TraceOut& r) {
+    if (dot3(d, hn) > 0.0f) hn = -hn;
+    r.dist = t;
+    r.ix = ix; r.iy = iy; r.iz = iz;
+    r.normal = hn;
+    r.iters = iters;
+}
+
 struct Hit { float closest; f3 normal; f3 albedo; int hit_light; int mat_id; };
 
 struct TraceStats { unsigned rays, iters, queries, closest_hits, sky_lookups; };
 VRT_DEV void stats_zero(TraceStats& s) { s.rays = s.iters = s.queries = s.closest_hits = s.sky_lookups = 0u; }
 
-// pathtracer.py:218-244 (floor plane 173-190, voxel grid 192-216).  SHADOW: no surface lookup.
-template <bool SHADOW, class PyrT>
-VRT_DEV void next_hit(const FrameParams& fp, const SceneData& sc, const PyrT& P, f3 pos, f3 d, Hit& h, TraceStats& ts) {
+VRT_DEV void hit_init(Hit& h) {
     h.closest = DM_INF;
     h.normal = mk3(0.0f);
     h.albedo = mk3(1.0f);
     h.hit_light = 0;
     h.mat_id = 0;
-    // infinite floor y = floor_height, accepted inside the radius-10 "disc" of pathtracer.py:183:
-    // the scalar dot(hit, up) = hit.y is subtracted from all three components
-    {
-        float t = (fp.floor_height - pos.y) / d.y;
-        if (t > VRT_EPS && t < h.closest) {
-            f3 hp = pos + d * t;
-            float s = hp.x * 0.0f + hp.y * 1.0f + hp.z * 0.0f;
-            if (len3(hp - s) < 10.0f) {
-                h.closest = t;
-                h.normal = mk3(0.0f, 1.0f, 0.0f);
-                if (dot3(h.normal, d) > 0.0f) h.normal = -h.normal;
-                h.albedo = fp.floor_color;
-                h.hit_light = (fp.floor_material == 2) ? 1 : 0;
-                h.mat_id = fp.floor_material;
-            }
-        }
+}
+// pathtracer.py:173-190: infinite floor y = floor_height, accepted inside the radius-10 "disc" of :183 -- the scalar
+// dot(hit, up) = hit.y is subtracted from all three components.  Returns the hit distance, inf for no hit.
+VRT_DEV float floor_probe(const FrameParams& fp, f3 pos, f3 d) {
+    const float t = (fp.floor_height - pos.y) / d.y;
+    if (t > VRT_EPS && t < DM_INF) {
+        const f3 hp = pos + d * t;
+        const float s = hp.x * 0.0f + hp.y * 1.0f + hp.z * 0.0f;
+        if (len3(hp - s) < 10.0f) return t;
     }
-    const float voxel_size = 1.0f / 64.0f, voxel_inv_size = 64.0f;
-    f3 eye = voxel_inv_size * pos - (-64.0f);
-    TraceOut tr;
-    int nq;
-    raytrace(P, eye, d, tr, nq);
-    ts.rays += 1u; ts.iters += (unsigned)tr.iters; ts.queries += (unsigned)nq;
-    VRT_REGION(SHADOW ? 3 : 9);  // ray set-up + result (one entry per ray)
+    return DM_INF;
+}
+VRT_DEV void hit_floor(const FrameParams& fp, f3 d, float t, Hit& h) {
+    h.closest = t;
+    h.normal = mk3(0.0f, 1.0f, 0.0f);
+    if (dot3(h.normal, d) > 0.0f) h.normal = -h.normal;
+    h.albedo = fp.floor_color;
+    h.hit_light = (fp.floor_material == 2) ? 1 : 0;
+    h.mat_id = fp.floor_material;
+}
+VRT_DEV f3 world_to_voxel(f3 pos) { return 64.0f * pos - (-64.0f); }  // pathtracer.py:165-171
+// pathtracer.py:203-216 + voxel_world.py:34-56: the walk's result against what is closest so far.  SHADOW: no surface lookup.
+template <bool SHADOW>
+VRT_DEV void hit_voxel(const FrameParams& fp, const SceneData& sc, f3 eye, f3 d, const TraceOut& tr, Hit& h, TraceStats& ts) {
+    const float voxel_size = 1.0f / 64.0f;
     if (tr.dist * voxel_size < h.closest) {
         h.closest = tr.dist * voxel_size;
         if (!SHADOW) {
@@ -210,6 +334,21 @@ VRT_DEV void next_hit(const FrameParams& fp, const SceneData& sc, const PyrT& P,
             h.normal = tr.normal;
         }
     }
+}
+
+// pathtracer.py:218-244 (floor plane 173-190, voxel grid 192-216).
+template <bool SHADOW, class PyrT>
+VRT_DEV void next_hit(const FrameParams& fp, const SceneData& sc, const PyrT& P, f3 pos, f3 d, Hit& h, TraceStats& ts) {
+    hit_init(h);
+    const float ft = floor_probe(fp, pos, d);
+    if (ft < DM_INF) hit_floor(fp, d, ft, h);
+    const f3 eye = world_to_voxel(pos);
+    TraceOut tr;
+    int nq;
+    raytrace(P, eye, d, tr, nq);
+    ts.rays += 1u; ts.iters += (unsigned)tr.iters; ts.queries += (unsigned)nq;
+    VRT_REGION(SHADOW ? 3 : 9);  // ray set-up + result (one entry per ray)
+    hit_voxel<SHADOW>(fp, sc, eye, d, tr, h, ts);
 }
 
 }  // namespace vrt

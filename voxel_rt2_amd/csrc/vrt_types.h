@@ -75,8 +75,8 @@ VRT_DEV f4 mul4(const mat4& M, f4 v) {
 // active lanes -- where the issue slots of the divergent render kernel go.  Never defined in the shipped library.
 #if defined(VRT_DIAG_REGIONS) && defined(__HIPCC__)
 static __device__ unsigned long long g_vrt_region[64];
-#if defined(__HIP_DEVICE_COMPILE__)
-#define VRT_REGION(id)                                                                                              \
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VRT_DIAG_CLOCKS_ONLY)  // CLOCKS_ONLY: just the pooled kernel's stage clocks
+#define VRT_REGION(id)                                                                                             \
     do {                                                                                                            \
         unsigned long long m_ = __ballot(1);                                                                        \
         if ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (int)__ffsll((long long)m_) - 1) { \
