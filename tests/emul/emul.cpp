@@ -168,13 +168,15 @@ static void render_all_pool(Emu* c, const FrameParams& fp, const SceneData& sc, 
                     RayWalk w;
                     walk_load(s, w);
                     BrickCache bc{-1, 0ULL};
+                    CoarseWords cw;
+                    coarse_fetch(P, w.ix, w.iy, w.iz, cw);
                     const int iters0 = w.iters;
                     for (int k = 1;; k++) {
                         int nq;
-                        const bool fin = walk_trip(P, w, bc, nq);
+                        const bool fin = walk_trip(P, w, bc, cw, nq);
                         c->ts.queries += (unsigned)nq;
                         if (fin) break;
-                        if (k % 3 == 0) { walk_store(s, w); walk_load(s, w); bc.key = -1; }
+                        if (k % 3 == 0) { walk_store(s, w); walk_load(s, w); bc.key = -1; coarse_fetch(P, w.ix, w.iy, w.iz, cw); }
                     }
                     c->ts.iters += (unsigned)(w.iters - iters0);
                     walk_store(s, w);

@@ -63,12 +63,26 @@ __global__ void k_build_coarse(const unsigned long long* __restrict__ fine, unsi
 
 // ---- render ----------------------------------------------------------------------------------
 struct LdsPyramid {  // coarse levels in LDS, fine level through L2
+    static constexpr bool flat_descend = false;  // its kernels walk with few active lanes: descend()'s early outs win
     const unsigned long long* l0;
     const unsigned long long* l1;
     const unsigned long long* l2;
     __device__ __forceinline__ unsigned long long load_l0(int i) const { return l0[i]; }
     __device__ __forceinline__ unsigned long long load_l1(int i) const { return l1[i]; }
     __device__ __forceinline__ unsigned long long load_l2(int i) const { return l2[i]; }
+};
+struct LdsPyramid2 {  // as LdsPyramid, with each l1 word stored beside its parent l2 word: {w1, w2}[512]
+    static constexpr bool flat_descend = true;   // the pooled kernel walks with nearly full waves
+    const unsigned long long* l0;
+    const ulonglong2* l12;
+    const unsigned long long* l2;
+    __device__ __forceinline__ unsigned long long load_l0(int i) const { return l0[i]; }
+    __device__ __forceinline__ unsigned long long load_l1(int i) const { return l12[i].x; }
+    __device__ __forceinline__ unsigned long long load_l2(int i) const { return l2[i]; }
+    __device__ __forceinline__ void load_coarse(int i1, unsigned long long& w1, unsigned long long& w2) const {
+        const ulonglong2 v = l12[i1];
+        w1 = v.x; w2 = v.y;
+    }
 };
 
 __device__ __forceinline__ void flush_stats(const TraceStats& ts, Counters* c) {
@@ -170,7 +184,7 @@ __global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_re
 #ifndef VRT_POOL_PARK
 #define VRT_POOL_PARK 16     // WALK: with the list empty, suspend the walks still going once this few are left
 #endif
-#define VRT_POOL_WORDS (VRT_POOL_SLOTS / 64)
+#define VRT_POOL_WORDS ((VRT_POOL_SLOTS + 63) / 64)   // state words per lane; slots past VRT_POOL_SLOTS are void (state 4)
 
 __device__ __forceinline__ void wave_lds_sync() {  // LDS written by some lanes of this wave, read by others
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -183,13 +197,18 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
 
 template <bool INSTR>
 __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_render_pool(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold) {
-    __shared__ unsigned long long s_l1[512];
+    __shared__ ulonglong2 s_l12[512];
     __shared__ unsigned long long s_l2[8];
     __shared__ float s_mats[128 * 14];
     __shared__ uint32_t s_pool[VRT_POOL_WAVES][PF_COUNT * VRT_POOL_SLOTS];
-    __shared__ uint32_t s_state[VRT_POOL_WAVES][VRT_POOL_SLOTS];
+    __shared__ uint32_t s_state[VRT_POOL_WAVES][VRT_POOL_WORDS * 64];
     __shared__ uint32_t s_list[VRT_POOL_WAVES][VRT_POOL_SLOTS];
-    for (int i = threadIdx.x; i < 512; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) {
+        ulonglong2 v;
+        v.x = sc.pyr.l1[i];
+        v.y = sc.pyr.l2[(((i >> 8) & 1) << 2) | (((i >> 5) & 1) << 1) | ((i >> 2) & 1)];
+        s_l12[i] = v;
+    }
     if (threadIdx.x < 8) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
     for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
     if (blockIdx.x == 0 && threadIdx.x == 0) *next_counter = 0u;  // the next launch's counter (idle during this launch)
@@ -197,10 +216,10 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
     uint32_t* const pool = s_pool[wave];
     uint32_t* const state = s_state[wave];
     uint32_t* const list = s_list[wave];
-    for (int k = 0; k < VRT_POOL_WORDS; k++) state[k * 64 + lane] = SLOT_EMPTY;
+    for (int k = 0; k < VRT_POOL_WORDS; k++) state[k * 64 + lane] = (k * 64 + lane < VRT_POOL_SLOTS) ? (uint32_t)SLOT_EMPTY : 4u;
     __syncthreads();
-    LdsPyramid P;
-    P.l0 = sc.pyr.l0; P.l1 = s_l1; P.l2 = s_l2;
+    LdsPyramid2 P;
+    P.l0 = sc.pyr.l0; P.l12 = s_l12; P.l2 = s_l2;
     SceneData scl = sc;
     scl.mats = s_mats;
     uint32_t* const cold_wave = cold + (size_t)(blockIdx.x * VRT_POOL_WAVES + wave) * VRT_POOL_SLOTS * PC_COUNT;
@@ -263,6 +282,8 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
             RayWalk w;
             BrickCache bc;
             bc.key = -1; bc.word = 0ULL;
+            CoarseWords cw;
+            cw.w1 = 0ULL; cw.w2 = 0ULL;
             SlotRef s;
             s.base = pool; s.stride = VRT_POOL_SLOTS;
             int slot = 0, iters0 = 0;
@@ -294,6 +315,7 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
                         slot = (int)list[idx];
                         s.base = pool + slot;
                         walk_load(s, w);
+                        coarse_fetch(P, w.ix, w.iy, w.iz, cw);
                         bc.key = -1;
                         iters0 = w.iters;
                         active = true;
@@ -305,7 +327,7 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
                 do {
                     if (active) {
                         int nq;
-                        if (walk_trip(P, w, bc, nq)) { active = false; ended = true; }
+                        if (walk_trip(P, w, bc, cw, nq)) { active = false; ended = true; }
                         ts.queries += (unsigned)nq;
                     }
                 } while (__popcll(__ballot(!active)) < target);

@@ -82,14 +82,22 @@ VRT_DEV unsigned brick_two_lods(unsigned long long w, int cx, int cy, int cz) {
 // walk stops at is the highest empty level at or below the starting one: a complement, a mask, a count-leading-
 // zeros.  (A wave with few active lanes, whose rays mostly stop at their first query, is better off with descend():
 // measured 3-10 % on the fused kernel.)
+struct CoarseWords { unsigned long long w1, w2; };  // the l1 and l2 brick words a cell falls in
+
+// Both coarse words of LOD-0 cell (x,y,z) in one request (one 16-byte LDS read in the kernels).  They depend on
+// the cell only, so the WALK loop asks for the next cell's words at the end of a step and meets them a step later.
 template <class PyrT>
-VRT_DEV int descend_flat(const PyrT& P, int x, int y, int z, int lod, bool& solid, BrickCache& bc, int& nq) {
+VRT_DEV void coarse_fetch(const PyrT& P, int x, int y, int z, CoarseWords& c) {
+    const int xm = x & (VRT_GRID - 1), ym = y & (VRT_GRID - 1), zm = z & (VRT_GRID - 1);  // keeps the table index in range
+    P.load_coarse((((zm >> 4) << 3) | (ym >> 4)) << 3 | (xm >> 4), c.w1, c.w2);
+}
+
+template <class PyrT>
+VRT_DEV int descend_flat(const PyrT& P, const CoarseWords& c, int x, int y, int z, int lod, bool& solid, BrickCache& bc, int& nq) {
     const bool inside = ((x | y | z) & ~(VRT_GRID - 1)) == 0;  // outside the grid: empty, as in descend()
-    const int xm = x & (VRT_GRID - 1), ym = y & (VRT_GRID - 1), zm = z & (VRT_GRID - 1);  // keeps the table indices in range
-    const unsigned long long w2 = P.load_l2((((zm >> 6) << 1) | (ym >> 6)) << 1 | (xm >> 6));
-    const unsigned long long w1 = P.load_l1((((zm >> 4) << 3) | (ym >> 4)) << 3 | (xm >> 4));
-    unsigned occ = (w2 != 0ULL ? 64u : 0u) | (brick_two_lods(w2, xm >> 4, ym >> 4, zm >> 4) << 4) |
-                   (brick_two_lods(w1, xm >> 2, ym >> 2, zm >> 2) << 2);
+    const int xm = x & (VRT_GRID - 1), ym = y & (VRT_GRID - 1), zm = z & (VRT_GRID - 1);
+    unsigned occ = (c.w2 != 0ULL ? 64u : 0u) | (brick_two_lods(c.w2, xm >> 4, ym >> 4, zm >> 4) << 4) |
+                   (brick_two_lods(c.w1, xm >> 2, ym >> 2, zm >> 2) << 2);
     const unsigned upto = (2u << lod) - 1u;  // levels 0..lod
     // the fine brick word matters only when every level from `lod` down to 2 is occupied
     if (inside && (~occ & upto & ~3u) == 0u) {
@@ -105,10 +113,15 @@ VRT_DEV int descend_flat(const PyrT& P, int x, int y, int z, int lod, bool& soli
 }
 
 struct GlobalPyramid {  // all three brick levels read from global memory
+    static constexpr bool flat_descend = false;
     Pyramid p;
     VRT_DEV unsigned long long load_l0(int i) const { return p.l0[i]; }
     VRT_DEV unsigned long long load_l1(int i) const { return p.l1[i]; }
     VRT_DEV unsigned long long load_l2(int i) const { return p.l2[i]; }
+    VRT_DEV void load_coarse(int i1, unsigned long long& w1, unsigned long long& w2) const {
+        w1 = p.l1[i1];
+        w2 = p.l2[(((i1 >> 8) & 1) << 2) | (((i1 >> 5) & 1) << 1) | ((i1 >> 2) & 1)];  // the l2 brick holding l1 brick i1
+    }
 };
 
 struct TraceOut { float dist; int ix, iy, iz; f3 normal; int iters; };
@@ -156,7 +169,13 @@ VRT_DEV void raytrace(const PyrT& P, f3 o, f3 d, TraceOut& r, int& queries) {
             bool solid;
             int nq;
             VRT_REGION(1);
-            lod = descend(P, ix, iy, iz, lod, solid, bc, nq);
+            if constexpr (PyrT::flat_descend) {  // the pyramid type says which descent suits its kernel (see descend_flat)
+                CoarseWords c;
+                coarse_fetch(P, ix, iy, iz, c);
+                lod = descend_flat(P, c, ix, iy, iz, lod, solid, bc, nq);
+            } else {
+                lod = descend(P, ix, iy, iz, lod, solid, bc, nq);
+            }
             queries += nq;
             if (solid) break;
 
@@ -227,19 +246,16 @@ VRT_DEV bool walk_prepare(f3 o, f3 d, RayWalk& w) {
     return true;
 }
 
-// One pass of the loop raytracer.py:103-147.  True = the walk is over (hit, miss or 512 steps).
+// One pass of the loop raytracer.py:103-147.  True = the walk is over (hit, miss or 512 steps).  `c` holds the
+// coarse words of the walk's current cell (coarse_fetch) on entry and of its next cell on return.
 template <class PyrT>
-VRT_DEV bool walk_trip(const PyrT& P, RayWalk& w, BrickCache& bc, int& nq) {
+VRT_DEV bool walk_trip(const PyrT& P, RayWalk& w, BrickCache& bc, CoarseWords& c, int& nq) {
     nq = 0;
     if (w.iters >= 512) return true;
     if (w.t > w.far) { w.t = DM_INF; return true; }
     bool solid;
     VRT_REGION(1);
-#if defined(VRT_WALK_BRANCHY)
-    w.lod = descend(P, w.ix, w.iy, w.iz, w.lod, solid, bc, nq);
-#else
-    w.lod = descend_flat(P, w.ix, w.iy, w.iz, w.lod, solid, bc, nq);
-#endif
+    w.lod = descend_flat(P, c, w.ix, w.iy, w.iz, w.lod, solid, bc, nq);
     if (solid) return true;
     const int lod = w.lod;
     const f3 d = w.d;
@@ -257,6 +273,7 @@ VRT_DEV bool walk_trip(const PyrT& P, RayWalk& w, BrickCache& bc, int& nq) {
     w.hn = mk3(t.x == min_t ? 1.0f : 0.0f, t.y == min_t ? 1.0f : 0.0f, t.z == min_t ? 1.0f : 0.0f) * w.sd;
     const f3 nxt = cell_base + edge + w.hn;
     w.ix = (int)nxt.x; w.iy = (int)nxt.y; w.iz = (int)nxt.z;
+    coarse_fetch(P, w.ix, w.iy, w.iz, c);
     w.lod = (lod + 1 > 6) ? 6 : lod + 1;
     w.iters += 1;
     return false;
