@@ -13,7 +13,7 @@ split into N contiguous row tiles (strong scaling: the frame is fixed), every ra
 tile with no data-path communication, and the HDR tiles are gathered to rank 0 over RCCL at the
 end of every step (inside the timed region).
 
-Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel (k_render)
+Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel (k_render_pool)
 and the CPU-oracle baseline timed on this box's host cores.
 """
 import argparse
@@ -189,10 +189,12 @@ def main():
         samples_per_launch = st["path_samples"] / launches  # a launch renders own_px pixels x the fused samples
         achieved = bytes_per_sample * samples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
+        # the render stage runs the pooled schedule (k_render_pool) unless VRT_RENDER=fused asks for the fused one
+        render_kernel = "k_render" if os.environ.get("VRT_RENDER") == "fused" else "k_render_pool"
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("k_render_bytes_per_launch")
+                traffic = json.load(open(tfile)).get(f"{render_kernel}_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -203,7 +205,7 @@ def main():
                                    "static camera, ReSTIR off", "width": WIDTH, "height": HEIGHT, "spp_per_step": SPP_PER_STEP,
                        "max_depth": MAX_DEPTH, "seed": SEED, "sharding": (f"{world} contiguous row tiles, boundaries balanced by measured tile cost, RCCL gather per step; "
                                     f"tile rows {[b - a for a, b in bounds]}") if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": "k_render", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": render_kernel, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_path_sample": round(bytes_per_sample, 2),
                          "queries_per_path_sample": round(q, 2), "closest_hits_per_path_sample": round(hc, 3),

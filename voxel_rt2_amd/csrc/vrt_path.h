@@ -199,10 +199,10 @@ VRT_DEV bool path_shade(const FrameParams& fp, const SceneData& sc, const PyrT& 
         p.sky_primary = (h.closest == DM_INF) ? 1 : 0;
         p.primary_pos = ppos;
         if (p.sample == 0) {  // the samples of one accumulate(n) call share camera and jitter: same primary vertex
-            out.gb_normal[local_idx] = oct_encode(h.normal);
-            out.gb_position[local_idx] = ppos;
-            out.gb_mat[local_idx] = p.primary_mat_info;
-            out.gb_depth[local_idx] = view_to_screen(xform(fp.view, ppos, 1.0f), fp.proj).z;
+            stream_store(&out.gb_normal[local_idx], oct_encode(h.normal));
+            stream_store3(&out.gb_position[local_idx], ppos);
+            stream_store(&out.gb_mat[local_idx], p.primary_mat_info);
+            stream_store(&out.gb_depth[local_idx], view_to_screen(xform(fp.view, ppos, 1.0f), fp.proj).z);
         }
     } else if (depth == 1) {
         if (p.first_lobe != LOBE_DIFFUSE) p.refl_dist += h.closest;
@@ -350,7 +350,7 @@ VRT_DEV void path_finish(const FrameParams& fp, const SceneData& sc, const Pixel
         const f3 vp = primary_pos + pdir * p.refl_dist;
         refl = linearize_depth(view_to_screen(xform(fp.view, vp, 1.0f), fp.proj).z, fp.proj_inv);
     }
-    out.gb_refl_depth[plane] = refl;
+    stream_store(&out.gb_refl_depth[plane], refl);
 
     f3 diffuse = mk3(0.0f), specular = mk3(0.0f);
     if constexpr (!RESTIR) {
@@ -364,8 +364,8 @@ VRT_DEV void path_finish(const FrameParams& fp, const SceneData& sc, const Pixel
     } else {
         restir_finish(fp, sc, out, local_idx, p, primary_pos, diffuse, specular, ts);
     }
-    out.color_d[plane] = diffuse;
-    out.color_s[plane] = specular;
+    stream_store3(&out.color_d[plane], diffuse);
+    stream_store3(&out.color_s[plane], specular);
 }
 
 }  // namespace vrt

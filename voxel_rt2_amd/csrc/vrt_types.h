@@ -61,6 +61,18 @@ VRT_DEV bool near_zero3(f3 v) { return dot3(v, v) < 1e-7f; }
 VRT_DEV float lum(f3 c) { return dot3(mk3(0.2125f, 0.7154f, 0.0721f), c); }
 VRT_DEV f3 firefly(f3 v) { return clamp3(v, 0.0f, 300.0f); }
 
+// Per-pixel results the render kernel writes once and never reads back: streamed (non-temporal) on the device so
+// that they do not push the pooled kernel's scratch lines and the brick words out of L2.
+template <class T>
+VRT_DEV void stream_store(T* p, T v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+VRT_DEV void stream_store3(f3* p, f3 v) { stream_store(&p->x, v.x); stream_store(&p->y, v.y); stream_store(&p->z, v.z); }
+
 struct mat4 { float m[16]; };  // row-major, m[row*4+col]
 VRT_DEV f4 mul4(const mat4& M, f4 v) {
     return mk4(M.m[0] * v.x + M.m[1] * v.y + M.m[2] * v.z + M.m[3] * v.w,
