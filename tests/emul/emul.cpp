@@ -23,7 +23,8 @@ struct Emu {
     vrt_scene_params scene;
     vrt_camera cam;
     std::vector<uint32_t> grid;
-    std::vector<unsigned long long> l0, l1, l2;
+    std::vector<unsigned long long> l0, l1, l2, l0c;
+    std::vector<uint32_t> l0c_base;  // [512] + count
     std::vector<float> mats, sky_scat, sky_trans;
     int buf0, buf1, own0, own1;
     size_t n;
@@ -121,6 +122,18 @@ int emu_upload_voxels(Emu* c, const int8_t* mat, const uint8_t* rgb) {
     };
     coarse(c->l0, c->l1, 8);
     coarse(c->l1, c->l2, 2);
+    // k_build_l0c: the fine level without its empty words
+    c->l0c.assign(32768, 0ULL);
+    c->l0c_base.assign(513, 0u);
+    uint32_t k = 0;
+    for (int i = 0; i < 512; i++) {
+        c->l0c_base[i] = k;
+        int bx1 = i & 7, by1 = (i >> 3) & 7, bz1 = i >> 6;
+        for (int b = 0; b < 64; b++)
+            if ((c->l1[i] >> b) & 1ULL)
+                c->l0c[k++] = c->l0[((bz1 * 4 + (b >> 4)) * 32 + (by1 * 4 + ((b >> 2) & 3))) * 32 + (bx1 * 4 + (b & 3))];
+    }
+    c->l0c_base[512] = k;
     return 0;
 }
 int emu_upload_materials(Emu* c, const float* t) { memcpy(c->mats.data(), t, 128 * 14 * 4); return 0; }
@@ -197,6 +210,7 @@ int emu_accumulate(Emu* c, int n_samples) {
         FrameParams fp = frame_params(c);
         SceneData sc;
         sc.pyr.l0 = c->l0.data(); sc.pyr.l1 = c->l1.data(); sc.pyr.l2 = c->l2.data();
+        sc.pyr.l0c = c->l0c.data(); sc.pyr.l0c_base = c->l0c_base.data(); sc.pyr.l0c_count = c->l0c_base.data() + 512;
         sc.grid = c->grid.data(); sc.mats = c->mats.data();
         sc.sky.scattering = c->sky_scat.data(); sc.sky.transmittance = c->sky_trans.data();
         sc.sky.res = c->cfg.sky_res; sc.sky.fres = c->cfg.sky_res > 0 ? (float)(1.0 / (double)c->cfg.sky_res) : 0.0f;

@@ -14,6 +14,17 @@ BUFS = (_abi.BUF_GBUF_DEPTH, _abi.BUF_GBUF_NORMAL, _abi.BUF_GBUF_POSITION, _abi.
         _abi.BUF_HISTORY_DIFFUSE, _abi.BUF_HISTORY_SPECULAR)
 
 
+@pytest.fixture(autouse=True, params=["fused", "pool"])
+def render_schedule(request, monkeypatch):
+    """Both schedules of the render stage: path_segment per pixel (vrt_path.h) and the pooled kernel's stage
+    functions stepped through their packed LDS slot, walks suspended and resumed every third step (vrt_pool.h)."""
+    if request.param == "pool":
+        monkeypatch.setenv("VRT_EMU_POOL", "1")
+    else:
+        monkeypatch.delenv("VRT_EMU_POOL", raising=False)
+    return request.param
+
+
 def pair(scene, W, H, depth, seed, restir=False, rows=None):
     mat, rgb, params = scenes.SCENES[scene](0)
     cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=depth, seed=seed,

@@ -48,7 +48,8 @@ struct vrt_ctx {
     size_t npix = 0;          // (buf1 - buf0) * W
     // scene data
     int8_t* d_mat = nullptr; uint8_t* d_rgb = nullptr; uint32_t* d_grid = nullptr;
-    unsigned long long *d_l0 = nullptr, *d_l1 = nullptr, *d_l2 = nullptr;
+    unsigned long long *d_l0 = nullptr, *d_l1 = nullptr, *d_l2 = nullptr, *d_l0c = nullptr;
+    uint32_t* d_l0c_base = nullptr;  // [512] offsets + [1] count
     float* d_mats = nullptr;
     Counters* d_counters = nullptr;
     unsigned* d_work = nullptr;
@@ -140,6 +141,7 @@ static FrameParams make_frame_params(const vrt_ctx* c) {
 static SceneData make_scene_data(const vrt_ctx* c) {
     SceneData sc;
     sc.pyr.l0 = c->d_l0; sc.pyr.l1 = c->d_l1; sc.pyr.l2 = c->d_l2;
+    sc.pyr.l0c = c->d_l0c; sc.pyr.l0c_base = c->d_l0c_base; sc.pyr.l0c_count = c->d_l0c_base + 512;
     sc.grid = c->d_grid;
     sc.mats = c->d_mats;
     sc.sky.scattering = c->d_sky_scat;
@@ -205,7 +207,8 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     const size_t nvox = (size_t)128 * 128 * 128, n = c->npix;
     ok = ok && dalloc(&c->d_mat, nvox) == hipSuccess && dalloc(&c->d_rgb, nvox * 3) == hipSuccess && dalloc(&c->d_grid, nvox) == hipSuccess;
-    ok = ok && dalloc(&c->d_l0, 32768) == hipSuccess && dalloc(&c->d_l1, 512) == hipSuccess && dalloc(&c->d_l2, 8) == hipSuccess;
+    ok = ok && dalloc(&c->d_l0, 32768) == hipSuccess && dalloc(&c->d_l1, 512) == hipSuccess && dalloc(&c->d_l2, 8) == hipSuccess &&
+         dalloc(&c->d_l0c, 32768) == hipSuccess && dalloc(&c->d_l0c_base, 513) == hipSuccess;
     ok = ok && dalloc(&c->d_mats, 128 * 14) == hipSuccess && dalloc(&c->d_counters, 1) == hipSuccess && dalloc(&c->d_work, 2) == hipSuccess;
     ok = ok && dalloc(&c->d_cbuf[0], n) == hipSuccess && dalloc(&c->d_cbuf[1], n) == hipSuccess && dalloc(&c->d_spec_planes, n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->d_gb_pos, n) == hipSuccess;
     ok = ok && dalloc(&c->d_gb_mat, n) == hipSuccess && dalloc(&c->d_refl_planes, n * VRT_MAX_FUSED) == hipSuccess;
@@ -247,7 +250,7 @@ void vrt_destroy(vrt_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     resolve_events(c);
-    void* ptrs[] = {c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_mats, c->d_counters, c->d_work, c->d_sky_scat,
+    void* ptrs[] = {c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l0c, c->d_l0c_base, c->d_mats, c->d_counters, c->d_work, c->d_sky_scat,
                     c->d_sky_trans, c->d_cloud_ambient, c->d_trans_lut, c->d_cloud_tex, c->d_cbuf[0], c->d_cbuf[1], c->d_spec_planes, c->d_color_d2,
                     c->d_color_s2, c->d_gb_pos, c->d_gb_normal[0], c->d_gb_normal[1], c->d_gb_depth[0], c->d_gb_depth[1],
                     c->d_gb_mat, c->d_refl_planes, c->d_gb_refl_f, c->d_hist_d[0], c->d_hist_d[1], c->d_hist_s[0], c->d_hist_s[1],
@@ -309,7 +312,7 @@ int vrt_set_instrumented(vrt_ctx* c, int on) {
 int vrt_prepare(vrt_ctx* c) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(launch_prepare(c->stream, c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2));
+    HIP_TRY(launch_prepare(c->stream, c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l0c, c->d_l0c_base));
     if (c->scene.use_physical_sky == 1) {
         SkyPrecompute sp = make_sky(c);
         f3 sd, sc_;

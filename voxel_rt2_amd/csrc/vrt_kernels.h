@@ -25,7 +25,7 @@
 namespace vrt {
 
 hipError_t launch_prepare(hipStream_t st, const int8_t* mat, const uint8_t* rgb, uint32_t* grid, unsigned long long* l0,
-                          unsigned long long* l1, unsigned long long* l2);
+                          unsigned long long* l1, unsigned long long* l2, unsigned long long* l0c, uint32_t* l0c_base);
 hipError_t query_render_residency(bool restir, bool instr, int* blocks_per_cu);
 hipError_t launch_render(hipStream_t st, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                          const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples);

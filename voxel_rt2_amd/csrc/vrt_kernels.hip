@@ -61,6 +61,35 @@ __global__ void k_build_coarse(const unsigned long long* __restrict__ fine, unsi
     coarse[b] = w;
 }
 
+// The fine level without its empty words (Pyramid::l0c, vrt_types.h).  One block of 512 threads, thread i = l1 brick i:
+// exclusive prefix sum of the popcounts, then each thread copies the words behind its set bits in bit order.
+__global__ void k_build_l0c(const unsigned long long* __restrict__ l0, const unsigned long long* __restrict__ l1,
+                            unsigned long long* __restrict__ l0c, uint32_t* __restrict__ base) {
+    __shared__ uint32_t s_scan[512];
+    const int i = threadIdx.x;
+    const unsigned long long w = l1[i];
+    const uint32_t cnt = (uint32_t)__popcll(w);
+    s_scan[i] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 512; off <<= 1) {  // Hillis-Steele inclusive scan
+        const uint32_t v = (i >= off) ? s_scan[i - off] : 0u;
+        __syncthreads();
+        s_scan[i] += v;
+        __syncthreads();
+    }
+    const uint32_t first = s_scan[i] - cnt;
+    base[i] = first;
+    if (i == 511) base[512] = s_scan[511];
+    const int bx1 = i & 7, by1 = (i >> 3) & 7, bz1 = i >> 6;
+    uint32_t k = first;
+    for (int b = 0; b < 64; b++) {
+        if ((w >> b) & 1ULL) {
+            const int bx = bx1 * 4 + (b & 3), by = by1 * 4 + ((b >> 2) & 3), bz = bz1 * 4 + (b >> 4);
+            l0c[k++] = l0[(bz * 32 + by) * 32 + bx];
+        }
+    }
+}
+
 // ---- render ----------------------------------------------------------------------------------
 struct LdsPyramid {  // coarse levels in LDS, fine level through L2
     static constexpr bool flat_descend = false;  // its kernels walk with few active lanes: descend()'s early outs win
@@ -71,17 +100,25 @@ struct LdsPyramid {  // coarse levels in LDS, fine level through L2
     __device__ __forceinline__ unsigned long long load_l1(int i) const { return l1[i]; }
     __device__ __forceinline__ unsigned long long load_l2(int i) const { return l2[i]; }
 };
-struct LdsPyramid2 {  // as LdsPyramid, with each l1 word stored beside its parent l2 word: {w1, w2}[512]
+// The pooled kernel's view: each l1 word beside its parent l2 word ({w1, w2}[512], one 16-byte LDS read per cell),
+// and the head of the compacted fine level (Pyramid::l0c) in LDS too -- a sparse scene's fine level is a few
+// hundred words, and the fine word is the load every other DDA step depends on (L2: ~700 cycles, LDS: ~130).
+struct LdsPyramid2 {
     static constexpr bool flat_descend = true;   // the pooled kernel walks with nearly full waves
     const unsigned long long* l0;
     const ulonglong2* l12;
     const unsigned long long* l2;
+    const uint32_t* fine_base;         // LDS copy of Pyramid::l0c_base
+    const unsigned long long* fine;    // LDS copy of l0c[0 .. n_fine)
+    uint32_t n_fine;
     __device__ __forceinline__ unsigned long long load_l0(int i) const { return l0[i]; }
     __device__ __forceinline__ unsigned long long load_l1(int i) const { return l12[i].x; }
     __device__ __forceinline__ unsigned long long load_l2(int i) const { return l2[i]; }
-    __device__ __forceinline__ void load_coarse(int i1, unsigned long long& w1, unsigned long long& w2) const {
+    __device__ __forceinline__ unsigned long long load_fine(int key, uint32_t idx) const { return idx < n_fine ? fine[idx] : l0[key]; }
+    __device__ __forceinline__ void load_coarse(int i1, unsigned long long& w1, unsigned long long& w2, uint32_t& base) const {
         const ulonglong2 v = l12[i1];
         w1 = v.x; w2 = v.y;
+        base = fine_base[i1];
     }
 };
 
@@ -184,6 +221,9 @@ __global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_re
 #ifndef VRT_POOL_PARK
 #define VRT_POOL_PARK 16     // WALK: with the list empty, suspend the walks still going once this few are left
 #endif
+#ifndef VRT_POOL_FINE_WORDS
+#define VRT_POOL_FINE_WORDS 1024   // fine brick words of the scene kept in LDS (8 KB): all of a sparse scene's
+#endif
 #define VRT_POOL_WORDS ((VRT_POOL_SLOTS + 63) / 64)   // state words per lane; slots past VRT_POOL_SLOTS are void (state 4)
 
 __device__ __forceinline__ void wave_lds_sync() {  // LDS written by some lanes of this wave, read by others
@@ -199,6 +239,8 @@ template <bool INSTR>
 __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_render_pool(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold) {
     __shared__ ulonglong2 s_l12[512];
     __shared__ unsigned long long s_l2[8];
+    __shared__ unsigned long long s_fine[VRT_POOL_FINE_WORDS];
+    __shared__ uint32_t s_fine_base[512];
     __shared__ float s_mats[128 * 14];
     __shared__ uint32_t s_pool[VRT_POOL_WAVES][PF_COUNT * VRT_POOL_SLOTS];
     __shared__ uint32_t s_state[VRT_POOL_WAVES][VRT_POOL_WORDS * 64];
@@ -208,8 +250,12 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
         v.x = sc.pyr.l1[i];
         v.y = sc.pyr.l2[(((i >> 8) & 1) << 2) | (((i >> 5) & 1) << 1) | ((i >> 2) & 1)];
         s_l12[i] = v;
+        s_fine_base[i] = sc.pyr.l0c_base[i];
     }
     if (threadIdx.x < 8) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
+    uint32_t n_fine = *sc.pyr.l0c_count;  // non-empty fine words of the scene; the first VRT_POOL_FINE_WORDS live in LDS
+    if (n_fine > VRT_POOL_FINE_WORDS) n_fine = VRT_POOL_FINE_WORDS;
+    for (uint32_t i = threadIdx.x; i < n_fine; i += blockDim.x) s_fine[i] = sc.pyr.l0c[i];
     for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
     if (blockIdx.x == 0 && threadIdx.x == 0) *next_counter = 0u;  // the next launch's counter (idle during this launch)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -220,6 +266,7 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
     __syncthreads();
     LdsPyramid2 P;
     P.l0 = sc.pyr.l0; P.l12 = s_l12; P.l2 = s_l2;
+    P.fine_base = s_fine_base; P.fine = s_fine; P.n_fine = n_fine;
     SceneData scl = sc;
     scl.mats = s_mats;
     uint32_t* const cold_wave = cold + (size_t)(blockIdx.x * VRT_POOL_WAVES + wave) * VRT_POOL_SLOTS * PC_COUNT;
@@ -447,7 +494,7 @@ __global__ void k_detmath_probe(int op, int n, const float* a, const float* b, f
 #define VRT_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
 hipError_t launch_prepare(hipStream_t st, const int8_t* mat, const uint8_t* rgb, uint32_t* grid, unsigned long long* l0,
-                          unsigned long long* l1, unsigned long long* l2) {
+                          unsigned long long* l1, unsigned long long* l2, unsigned long long* l0c, uint32_t* l0c_base) {
     const int n = VRT_GRID * VRT_GRID * VRT_GRID;
     hipLaunchKernelGGL(k_pack_grid, dim3((n + 255) / 256), dim3(256), 0, st, mat, rgb, grid, n);
     VRT_LAUNCH_CHECK();
@@ -456,6 +503,8 @@ hipError_t launch_prepare(hipStream_t st, const int8_t* mat, const uint8_t* rgb,
     hipLaunchKernelGGL(k_build_coarse, dim3(2), dim3(256), 0, st, (const unsigned long long*)l0, l1, 8);
     VRT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_build_coarse, dim3(1), dim3(64), 0, st, (const unsigned long long*)l1, l2, 2);
+    VRT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_build_l0c, dim3(1), dim3(512), 0, st, (const unsigned long long*)l0, (const unsigned long long*)l1, l0c, l0c_base);
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }

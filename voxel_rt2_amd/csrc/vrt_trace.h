@@ -66,32 +66,36 @@ VRT_DEV int descend(const PyrT& P, int x, int y, int z, int lod, bool& solid, Br
 }
 
 // One 4x4x4 brick word answers two LODs for the cell (cx,cy,cz) of its finer level: bit 0 of the result = that
-// cell is occupied, bit 1 = the 2x2x2 block around it holds an occupied cell.  The z&2 half of the word is picked
-// first so that everything after it is 32-bit work (the 0x00330033 block mask shifted by at most 10 still fits).
+// cell is occupied, bit 1 = the 2x2x2 block around it holds an occupied cell.  One 64-bit shift brings the block to
+// the bottom of the word; what is left is 32-bit work.
 VRT_DEV unsigned brick_two_lods(unsigned long long w, int cx, int cy, int cz) {
-    const unsigned half = (cz & 2) ? (unsigned)(w >> 32) : (unsigned)w;
-    const unsigned cell = (half >> (((cz & 1) << 4) | ((cy & 3) << 2) | (cx & 3))) & 1u;
-    const unsigned block = (half & (0x00330033u << (((cy & 2) << 2) | (cx & 2)))) != 0u ? 2u : 0u;
+    const int bit = ((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3);   // the cell's bit
+    const unsigned u = (unsigned)(w >> (bit & 0x2a));               // word shifted down to the cell's 2x2x2 block: its 8 bits are 0x00330033
+    const unsigned cell = (u >> (bit & 0x15)) & 1u;
+    const unsigned block = (u & 0x00330033u) != 0u ? 2u : 0u;
     return block | cell;
+}
+
+// The coarse context of a LOD-0 cell: the l1 and l2 brick words it falls in and where the fine words behind that
+// l1 word start in the compacted fine level (Pyramid::l0c).
+struct CoarseWords { unsigned long long w1, w2; uint32_t fine_base; };
+
+// All of it in one request (one 16-byte and one 4-byte LDS read in the kernels).  It depends on the cell only, so
+// the WALK loop asks for the next cell's context at the end of a step and meets it a step later.
+template <class PyrT>
+VRT_DEV void coarse_fetch(const PyrT& P, int x, int y, int z, CoarseWords& c) {
+    const int xm = x & (VRT_GRID - 1), ym = y & (VRT_GRID - 1), zm = z & (VRT_GRID - 1);  // keeps the table index in range
+    P.load_coarse((((zm >> 4) << 3) | (ym >> 4)) << 3 | (xm >> 4), c.w1, c.w2, c.fine_base);
 }
 
 // descend() without the walk: same result, fixed cost.  descend() is a seven-way nest of branches; a wave whose
 // lanes sit at mixed LODs executes most of it (about 190 of the 256 instructions of a DDA step), which is what a
 // FULL wave of rays does -- the pooled schedule's WALK stage (vrt_pool.h).  Here the occupancy of all seven levels
-// of the cell is gathered into one 7-bit mask -- two LDS words and the cached fine brick word -- and the level the
-// walk stops at is the highest empty level at or below the starting one: a complement, a mask, a count-leading-
+// of the cell is gathered into one 7-bit mask -- the coarse context and the cached fine brick word -- and the level
+// the walk stops at is the highest empty level at or below the starting one: a complement, a mask, a count-leading-
 // zeros.  (A wave with few active lanes, whose rays mostly stop at their first query, is better off with descend():
-// measured 3-10 % on the fused kernel.)
-struct CoarseWords { unsigned long long w1, w2; };  // the l1 and l2 brick words a cell falls in
-
-// Both coarse words of LOD-0 cell (x,y,z) in one request (one 16-byte LDS read in the kernels).  They depend on
-// the cell only, so the WALK loop asks for the next cell's words at the end of a step and meets them a step later.
-template <class PyrT>
-VRT_DEV void coarse_fetch(const PyrT& P, int x, int y, int z, CoarseWords& c) {
-    const int xm = x & (VRT_GRID - 1), ym = y & (VRT_GRID - 1), zm = z & (VRT_GRID - 1);  // keeps the table index in range
-    P.load_coarse((((zm >> 4) << 3) | (ym >> 4)) << 3 | (xm >> 4), c.w1, c.w2);
-}
-
+// measured 3-10 % on the fused kernel.)  The fine word is asked for by its rank among the set bits of the l1 word,
+// which is where the compacted fine level keeps it (load_fine; a pyramid without one just indexes l0 by `key`).
 template <class PyrT>
 VRT_DEV int descend_flat(const PyrT& P, const CoarseWords& c, int x, int y, int z, int lod, bool& solid, BrickCache& bc, int& nq) {
     const bool inside = ((x | y | z) & ~(VRT_GRID - 1)) == 0;  // outside the grid: empty, as in descend()
@@ -102,7 +106,15 @@ VRT_DEV int descend_flat(const PyrT& P, const CoarseWords& c, int x, int y, int 
     // the fine brick word matters only when every level from `lod` down to 2 is occupied
     if (inside && (~occ & upto & ~3u) == 0u) {
         const int key = (((zm >> 2) << 5) | (ym >> 2)) << 5 | (xm >> 2);
-        if (key != bc.key) { bc.key = key; bc.word = P.load_l0(key); }
+        VRT_REGION(19);
+        if (key != bc.key) {
+            VRT_REGION(18);
+            const int bit = brick_bit(xm >> 2, ym >> 2, zm >> 2);  // of this fine brick in the l1 word
+            const unsigned long long below = c.w1 & ((1ULL << bit) - 1ULL);
+            bc.key = key;
+            bc.word = 0ULL;  // a walk that starts below LOD 2 can stand in an empty brick: nothing to load
+            if ((c.w1 >> bit) & 1ULL) bc.word = P.load_fine(key, c.fine_base + (uint32_t)__builtin_popcountll(below));
+        }
         occ |= brick_two_lods(bc.word, xm, ym, zm);
     }
     const unsigned empty = inside ? (~occ & upto) : upto;
@@ -118,9 +130,11 @@ struct GlobalPyramid {  // all three brick levels read from global memory
     VRT_DEV unsigned long long load_l0(int i) const { return p.l0[i]; }
     VRT_DEV unsigned long long load_l1(int i) const { return p.l1[i]; }
     VRT_DEV unsigned long long load_l2(int i) const { return p.l2[i]; }
-    VRT_DEV void load_coarse(int i1, unsigned long long& w1, unsigned long long& w2) const {
+    VRT_DEV unsigned long long load_fine(int key, uint32_t idx) const { (void)key; return p.l0c[idx]; }
+    VRT_DEV void load_coarse(int i1, unsigned long long& w1, unsigned long long& w2, uint32_t& fine_base) const {
         w1 = p.l1[i1];
         w2 = p.l2[(((i1 >> 8) & 1) << 2) | (((i1 >> 5) & 1) << 1) | ((i1 >> 2) & 1)];  // the l2 brick holding l1 brick i1
+        fine_base = p.l0c_base[i1];
     }
 };
 
@@ -257,10 +271,14 @@ VRT_DEV bool walk_trip(const PyrT& P, RayWalk& w, BrickCache& bc, CoarseWords& c
     VRT_REGION(1);
     w.lod = descend_flat(P, c, w.ix, w.iy, w.iz, w.lod, solid, bc, nq);
     if (solid) return true;
+    // The step of raytrace() with three of its values produced by cheaper, bit-identical means: 2^lod assembled from
+    // its exponent, the cell base as float(ix with its low lod bits cleared) (= float(ix >> lod) * 2^lod: both exact),
+    // and the step normal selected between sd and sd's signed zero (= {1, 0} * sd).
     const int lod = w.lod;
     const f3 d = w.d;
-    const float cell_size = (float)(1 << lod);
-    const f3 cell_base = mk3((float)(w.ix >> lod), (float)(w.iy >> lod), (float)(w.iz >> lod)) * cell_size;
+    const float cell_size = dm_u2f(0x3f800000u + ((uint32_t)lod << 23));
+    const int keep = ~((1 << lod) - 1);
+    const f3 cell_base = mk3((float)(w.ix & keep), (float)(w.iy & keep), (float)(w.iz & keep));
     const f3 fp = (w.o + d * w.t) - cell_base;
     f3 dist;
     dist.x = (d.x > 0.0f) ? cell_size - fp.x : fp.x;
@@ -270,7 +288,8 @@ VRT_DEV bool walk_trip(const PyrT& P, RayWalk& w, BrickCache& bc, CoarseWords& c
     const float min_t = dm_min(dm_min(t.x, t.y), t.z);
     const f3 edge = clamp3(floor3(fp + min_t * d), 0.0f, cell_size - 1.0f);
     w.t += min_t;
-    w.hn = mk3(t.x == min_t ? 1.0f : 0.0f, t.y == min_t ? 1.0f : 0.0f, t.z == min_t ? 1.0f : 0.0f) * w.sd;
+    w.hn = mk3(t.x == min_t ? w.sd.x : dm_u2f(dm_f2u(w.sd.x) & 0x80000000u), t.y == min_t ? w.sd.y : dm_u2f(dm_f2u(w.sd.y) & 0x80000000u),
+               t.z == min_t ? w.sd.z : dm_u2f(dm_f2u(w.sd.z) & 0x80000000u));
     const f3 nxt = cell_base + edge + w.hn;
     w.ix = (int)nxt.x; w.iy = (int)nxt.y; w.iz = (int)nxt.z;
     coarse_fetch(P, w.ix, w.iy, w.iz, c);

@@ -119,10 +119,16 @@ struct Counters { unsigned long long rays, iters, queries, closest_hits, sky_loo
 //   l1[ 8^3]: bit = l0 word non-zero     -> LOD 2 (bit), LOD 3 (sub-mask),       LOD 4 (word != 0)
 //   l2[ 2^3]: bit = l1 word non-zero     -> LOD 4 (bit), LOD 5 (sub-mask),       LOD 6 (word != 0)
 // Word index inside a level: (bz * n + by) * n + bx; bit inside a word: (z&3)*16 + (y&3)*4 + (x&3).
+// l0c is l0 without its empty words: the non-zero fine words in (l1 brick, bit) order, i.e. the word of the l0
+// brick behind set bit b of l1 word i sits at l0c[l0c_base[i] + popcount(l1[i] & ((1 << b) - 1))].  A sparse scene's
+// whole fine level is then a few KB and the pooled render kernel keeps (the head of) it in LDS.
 struct Pyramid {
     const unsigned long long* l0;
     const unsigned long long* l1;
     const unsigned long long* l2;
+    const unsigned long long* l0c;
+    const uint32_t* l0c_base;   // [512]
+    const uint32_t* l0c_count;  // [1]: non-empty l0 words
 };
 
 struct SkyTables {
