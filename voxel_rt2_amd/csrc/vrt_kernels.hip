@@ -142,7 +142,7 @@ __global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_re
     for (int i = threadIdx.x; i < 512; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
     if (threadIdx.x < 8) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
     for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *next_counter = 0u;  // the next launch's counter (idle during this launch)
+    if (blockIdx.x == 0 && threadIdx.x < VRT_WORK_HEADS) next_counter[threadIdx.x * VRT_WORK_HEAD_STRIDE] = 0u;  // the next launch's heads (idle during this launch)
     __syncthreads();
     LdsPyramid P;
     P.l0 = sc.pyr.l0; P.l1 = s_l1; P.l2 = s_l2;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
     if (n_fine > VRT_POOL_FINE_WORDS) n_fine = VRT_POOL_FINE_WORDS;
     for (uint32_t i = threadIdx.x; i < n_fine; i += blockDim.x) s_fine[i] = sc.pyr.l0c[i];
     for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *next_counter = 0u;  // the next launch's counter (idle during this launch)
+    if (blockIdx.x == 0 && threadIdx.x < VRT_WORK_HEADS) next_counter[threadIdx.x * VRT_WORK_HEAD_STRIDE] = 0u;  // the next launch's heads (idle during this launch)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* const pool = s_pool[wave];
     uint32_t* const state = s_state[wave];
@@ -277,6 +277,10 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
     TraceStats ts;
     stats_zero(ts);
     bool exhausted = false;  // wave-uniform
+    // items are split into VRT_WORK_HEADS contiguous ranges of whole tiles; this wave starts on its XCD's range
+    const unsigned range = ((total / 64u + VRT_WORK_HEADS - 1u) / VRT_WORK_HEADS) * 64u;
+    unsigned head = blockIdx.x & (VRT_WORK_HEADS - 1u);  // workgroups go round-robin over the 8 XCDs
+    int heads_left = VRT_WORK_HEADS;
 
 #if defined(VRT_DIAG_REGIONS)
     unsigned long long t_prev = __builtin_readcyclecounter();
@@ -381,11 +385,22 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
             }
         } else {
             const int take = n < 64 ? n : 64;
-            unsigned base = 0u;
+            unsigned base = 0u, limit = 0u;  // items [base, limit) go to lanes 0.. of this BEGIN
             if (stage == SLOT_EMPTY) {
-                if (lane == 0) base = atomicAdd(work_counter, (unsigned)take);
-                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                if (base + (unsigned)take >= total) exhausted = true;
+                // pull from the current head; a used-up range sends the wave on to the next head (and this BEGIN
+                // hands out nothing: the census runs again)
+                unsigned got = 0u;
+                if (lane == 0) got = atomicAdd(work_counter + head * VRT_WORK_HEAD_STRIDE, (unsigned)take);
+                got = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+                const unsigned r0 = head * range, r1 = (r0 + range < total) ? r0 + range : total;
+                base = r0 + got;
+                limit = (base + (unsigned)take < r1) ? base + (unsigned)take : r1;
+                if (r0 >= total || base + (unsigned)take >= r1) {
+                    heads_left -= 1;
+                    head = (head + 1u) & (VRT_WORK_HEADS - 1u);
+                    if (heads_left == 0) exhausted = true;
+                }
+                if (base > limit) base = limit;
             }
             if (lane < take) {
                 const int slot = (int)list[lane];
@@ -401,7 +416,7 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
                 } else {
                     VRT_REGION(13);
                     const unsigned my = base + (unsigned)lane;
-                    if (my < total) {
+                    if (my < limit) {
                         const unsigned group = my >> 6, in = my & 63u;
                         const unsigned tile = group / (unsigned)n_samples;
                         const int sample = (int)(group % (unsigned)n_samples);
@@ -521,8 +536,8 @@ hipError_t query_render_residency(bool restir, bool instr, int* blocks_per_cu) {
 hipError_t launch_render(hipStream_t st, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                          const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples) {
     // two counters alternate between launches: this launch counts on one and zeroes the other for the next launch
-    unsigned* work_counter = work_counters + (launch_seq & 1u);
-    unsigned* next_counter = work_counters + ((launch_seq + 1u) & 1u);
+    unsigned* work_counter = work_counters + (launch_seq & 1u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);  // the fused kernel uses head 0 only
+    unsigned* next_counter = work_counters + ((launch_seq + 1u) & 1u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     dim3 g(n_blocks), b(VRT_RENDER_THREADS);
     // pixels a wave reserves per atomic: whole 8x8 tiles.  One tile keeps the tail short (measured: 192-pixel chunks
     // cost 13 % at 1080p on the sparse scene) and still cuts the atomic rate ~3x against per-refill atomics, which
@@ -546,8 +561,8 @@ hipError_t query_render_pool_residency(bool instr, int* blocks_per_cu) {
 size_t pool_scratch_bytes(int n_blocks) { return (size_t)n_blocks * VRT_POOL_WAVES * VRT_POOL_SLOTS * PC_COUNT * sizeof(uint32_t); }
 hipError_t launch_render_pool(hipStream_t st, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                               const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold) {
-    unsigned* work_counter = work_counters + (launch_seq & 1u);
-    unsigned* next_counter = work_counters + ((launch_seq + 1u) & 1u);
+    unsigned* work_counter = work_counters + (launch_seq & 1u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
+    unsigned* next_counter = work_counters + ((launch_seq + 1u) & 1u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     dim3 g(n_blocks), b(64 * VRT_POOL_WAVES);
     if (instr) hipLaunchKernelGGL((k_render_pool<true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold);
     else hipLaunchKernelGGL((k_render_pool<false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold);
