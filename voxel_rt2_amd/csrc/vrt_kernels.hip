@@ -169,6 +169,7 @@ __global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_re
         if (mask != 0ULL && !exhausted) {
             // One returning atomic on a single word saturates near 88 dequeues/us chip-wide (MI355X_MICROARCH.md,
             // row `dequeue`): a wave therefore reserves `chunk` pixels at a time and hands them to its lanes itself.
+            // (Splitting the items over per-XCD heads, which the pooled kernel does, made THIS kernel 3-10 % slower.)
             if (chunk_next == chunk_end) {
                 unsigned base = 0u;
                 if (lane == 0) base = atomicAdd(work_counter, chunk);
@@ -285,10 +286,13 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
 #if defined(VRT_DIAG_REGIONS)
     unsigned long long t_prev = __builtin_readcyclecounter();
     int prev_stage = 4;  // 4 = start-up
+    // summed in registers and flushed once at the end: an atomic per stage switch from 2048 waves saturates the
+    // words it lands on and slows every other memory operation (it made the first version of this clock useless)
+    unsigned long long t_stage[6] = {0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
 #define VRT_POOL_CLOCK(next_stage)                                                                              \
     do {                                                                                                        \
         const unsigned long long t_now = __builtin_readcyclecounter();                                          \
-        if (lane == 0) atomicAdd(&g_vrt_region[2 * (20 + prev_stage)], t_now - t_prev);                         \
+        _Pragma("unroll") for (int q_ = 0; q_ < 6; q_++) if (prev_stage == q_) t_stage[q_] += t_now - t_prev;   \
         t_prev = t_now; prev_stage = (next_stage);                                                              \
     } while (0)
 #else
@@ -430,6 +434,10 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
         }
     }
     VRT_POOL_CLOCK(4);
+#if defined(VRT_DIAG_REGIONS)
+    if (lane == 0)
+        for (int q = 0; q < 6; q++) atomicAdd(&g_vrt_region[2 * (20 + q)], t_stage[q]);
+#endif
     if (INSTR) flush_stats(ts, sc.counters);
 }
 
