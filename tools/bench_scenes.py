@@ -22,6 +22,9 @@ CASES = [
     dict(name="s6_sky_clouds_1080p_d8_norestir", scene="s6", W=1920, H=1080, depth=8, spp=4, steps=5, sky_res=3840),
     dict(name="sunlit_restir_1080p_d8", scene="sunlit", W=1920, H=1080, depth=8, spp=4, steps=5, restir=True),
     dict(name="s6_nosky_restir_1080p_d8", scene="s6", W=1920, H=1080, depth=8, spp=4, steps=5, restir=True),
+    # one rank's share of an 8- and a 2-GPU run of config 2 (rows through the middle of the picture)
+    dict(name="shard_1of8_config2", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=20, rows=(472, 607)),
+    dict(name="shard_1of2_config2", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=20, rows=(0, 540)),
 ]
 
 
@@ -32,7 +35,7 @@ def run(case):
     if not sky_res:
         params = dict(params, use_physical_sky=0, use_clouds=0)
     cfg = host.make_config(case["W"], case["H"], voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=case["depth"],
-                           seed=0, use_restir=case.get("restir", False), sky_res=sky_res)
+                           seed=0, use_restir=case.get("restir", False), sky_res=sky_res, rows=case.get("rows"))
     s = NativeSession(lib, "vrt_", cfg)
     s.upload_voxels(mat, rgb)
     s.upload_materials(materials.load_table())
@@ -69,7 +72,8 @@ def run(case):
     ist = s.stats()
     n = ist["path_samples"]
     hdr = s.fetch_hdr()
-    out = dict(name=case["name"], mpaths_per_s=round(case["W"] * case["H"] * case["spp"] * case["steps"] / dt / 1e6, 1),
+    rows = case.get("rows") or (0, case["H"])
+    out = dict(name=case["name"], mpaths_per_s=round(case["W"] * (rows[1] - rows[0]) * case["spp"] * case["steps"] / dt / 1e6, 1),
                render_ms=round(st["render_ms"] / max(st["render_launches"], 1), 3),
                gris_ms=round(st["gris_ms"] / max(st["gris_launches"], 1), 3),
                temporal_ms=round(st["temporal_ms"] / max(st["temporal_launches"], 1), 3),

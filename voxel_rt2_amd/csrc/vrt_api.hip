@@ -65,14 +65,28 @@ struct vrt_ctx {
     f3* d_multi_d = nullptr;        // diffuse colour planes of the samples fused into one launch (allocated on first use)
     f3* d_spec_planes = nullptr;    // VRT_MAX_FUSED specular planes; d_color_s = the last one
     float* d_refl_planes = nullptr; // likewise for the raw reflection depth; d_gb_refl = the last one
-    uint32_t* d_gb_normal[2] = {nullptr, nullptr};
-    float* d_gb_depth[2] = {nullptr, nullptr};
+    uint32_t* d_gb_normal[4] = {nullptr, nullptr, nullptr, nullptr};  // rotating: [cur] is written by the next launch, [prev_gb] by the last
+    float* d_gb_depth[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t* d_gb_mat = nullptr;
     float *d_gb_refl = nullptr, *d_gb_refl_f = nullptr;
     f4 *d_hist_d[2] = {nullptr, nullptr}, *d_hist_s[2] = {nullptr, nullptr};
     f4* d_ldr = nullptr;
     ReservoirRec* d_res[2] = {nullptr, nullptr};
-    int cur = 0;      // g-buffer ping-pong: render writes [cur], temporal reads [cur ^ 1] as "prev"
+    int cur = 0;      // g-buffer rotation: render writes [cur], temporal reads [prev_gb] as "prev"
+    int prev_gb = 3;  // the copy the most recent launch wrote
+    // Overlapped launches (vrt_accumulate): VRT_SETS copies (set 0 = the canonical buffers, alt_*[s - 1] the others) of
+    // everything a render launch writes and its temporal pass reads, two render streams and the events that order
+    // them, so that launch k+1 starts while launch k drains and temporal pass k runs beside launch k+1.
+    f3* alt_multi_d[2] = {nullptr, nullptr}; f3* alt_spec_planes[2] = {nullptr, nullptr}; float* alt_refl_planes[2] = {nullptr, nullptr};
+    f3* alt_gb_pos[2] = {nullptr, nullptr}; uint32_t* alt_gb_mat[2] = {nullptr, nullptr};
+    uint32_t* alt_pool_scratch = nullptr;  // the second render stream's scratch
+    hipStream_t rstream[2] = {nullptr, nullptr};
+    hipEvent_t ev_r[3] = {nullptr, nullptr, nullptr}, ev_t[3] = {nullptr, nullptr, nullptr}, ev_main = nullptr;
+    bool ev_t_valid[3] = {false, false, false};
+    bool overlap_ready = false, overlap_failed = false;
+    bool main_dirty = true;   // work other than accumulate passes was queued on the main stream since the last overlapped launch
+    unsigned pipe_seq = 0;    // overlapped launches so far
+    int last_set = 0;         // copy (0 = the canonical buffers) the most recent render launch wrote
     int hist_in = 0;  // history ping-pong
     mat4 prev_view{}, prev_proj{};
     uint32_t frame = 0;
@@ -209,13 +223,13 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
     ok = ok && dalloc(&c->d_mat, nvox) == hipSuccess && dalloc(&c->d_rgb, nvox * 3) == hipSuccess && dalloc(&c->d_grid, nvox) == hipSuccess;
     ok = ok && dalloc(&c->d_l0, 32768) == hipSuccess && dalloc(&c->d_l1, 512) == hipSuccess && dalloc(&c->d_l2, 8) == hipSuccess &&
          dalloc(&c->d_l0c, 32768) == hipSuccess && dalloc(&c->d_l0c_base, 513) == hipSuccess;
-    ok = ok && dalloc(&c->d_mats, 128 * 14) == hipSuccess && dalloc(&c->d_counters, 1) == hipSuccess && dalloc(&c->d_work, 2 * VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE) == hipSuccess;
+    ok = ok && dalloc(&c->d_mats, 128 * 14) == hipSuccess && dalloc(&c->d_counters, 1) == hipSuccess && dalloc(&c->d_work, 4 * VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE) == hipSuccess;
     ok = ok && dalloc(&c->d_cbuf[0], n) == hipSuccess && dalloc(&c->d_cbuf[1], n) == hipSuccess && dalloc(&c->d_spec_planes, n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->d_gb_pos, n) == hipSuccess;
     ok = ok && dalloc(&c->d_gb_mat, n) == hipSuccess && dalloc(&c->d_refl_planes, n * VRT_MAX_FUSED) == hipSuccess;
     if (ok) { c->d_color_s = c->d_spec_planes + (size_t)(VRT_MAX_FUSED - 1) * n; c->d_gb_refl = c->d_refl_planes + (size_t)(VRT_MAX_FUSED - 1) * n; }
     ok = ok && dalloc(&c->d_gb_refl_f, n) == hipSuccess && dalloc(&c->d_ldr, n) == hipSuccess;
+    for (int s = 0; s < 4 && ok; s++) ok = ok && dalloc(&c->d_gb_normal[s], n) == hipSuccess && dalloc(&c->d_gb_depth[s], n) == hipSuccess;
     for (int s = 0; s < 2 && ok; s++) {
-        ok = ok && dalloc(&c->d_gb_normal[s], n) == hipSuccess && dalloc(&c->d_gb_depth[s], n) == hipSuccess;
         ok = ok && dalloc(&c->d_hist_d[s], n) == hipSuccess && dalloc(&c->d_hist_s[s], n) == hipSuccess;
         if (cfg->use_restir) ok = ok && dalloc(&c->d_res[s], n) == hipSuccess;
     }
@@ -248,9 +262,19 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
 void vrt_destroy(vrt_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    for (int s = 0; s < 2; s++) if (c->rstream[s]) hipStreamSynchronize(c->rstream[s]);
     if (c->stream) hipStreamSynchronize(c->stream);
     resolve_events(c);
-    void* ptrs[] = {c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l0c, c->d_l0c_base, c->d_mats, c->d_counters, c->d_work, c->d_sky_scat,
+    for (int s = 0; s < 3; s++) {
+        if (c->ev_r[s]) hipEventDestroy(c->ev_r[s]);
+        if (c->ev_t[s]) hipEventDestroy(c->ev_t[s]);
+    }
+    for (int s = 0; s < 2; s++) if (c->rstream[s]) hipStreamDestroy(c->rstream[s]);
+    if (c->ev_main) hipEventDestroy(c->ev_main);
+    void* ptrs[] = {c->alt_multi_d[0], c->alt_spec_planes[0], c->alt_refl_planes[0], c->alt_gb_pos[0], c->alt_gb_mat[0],
+                    c->alt_multi_d[1], c->alt_spec_planes[1], c->alt_refl_planes[1], c->alt_gb_pos[1], c->alt_gb_mat[1],
+                    c->alt_pool_scratch, c->d_gb_normal[2], c->d_gb_depth[2], c->d_gb_normal[3], c->d_gb_depth[3],
+                    c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l0c, c->d_l0c_base, c->d_mats, c->d_counters, c->d_work, c->d_sky_scat,
                     c->d_sky_trans, c->d_cloud_ambient, c->d_trans_lut, c->d_cloud_tex, c->d_cbuf[0], c->d_cbuf[1], c->d_spec_planes, c->d_color_d2,
                     c->d_color_s2, c->d_gb_pos, c->d_gb_normal[0], c->d_gb_normal[1], c->d_gb_depth[0], c->d_gb_depth[1],
                     c->d_gb_mat, c->d_refl_planes, c->d_gb_refl_f, c->d_hist_d[0], c->d_hist_d[1], c->d_hist_s[0], c->d_hist_s[1],
@@ -312,6 +336,7 @@ int vrt_set_instrumented(vrt_ctx* c, int on) {
 int vrt_prepare(vrt_ctx* c) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    c->main_dirty = true;
     HIP_TRY(launch_prepare(c->stream, c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l0c, c->d_l0c_base));
     if (c->scene.use_physical_sky == 1) {
         SkyPrecompute sp = make_sky(c);
@@ -334,6 +359,7 @@ int vrt_sky_accumulate_clouds(vrt_ctx* c, int max_samples) {
     f3 sd, sc_;
     float cm;
     sun_of(c, sd, sc_, cm);
+    c->main_dirty = true;
     HIP_TRY(launch_sky_clouds(c->stream, make_sky(c), sd, sc_, cm, max_samples, c->cloud_pass));
     c->cloud_pass++;
     return VRT_OK;
@@ -346,6 +372,7 @@ int vrt_sky_compute_slice(vrt_ctx* c, int slice_idx, int max_slices) {
     float cm;
     sun_of(c, sd, sc_, cm);
     int w = c->cfg.sky_res / max_slices;  // atmos.py:162
+    c->main_dirty = true;
     HIP_TRY(launch_sky_slice(c->stream, make_sky(c), sd, sc_, cm, w * slice_idx, w * (slice_idx + 1)));
     return VRT_OK;
 }
@@ -355,6 +382,26 @@ static int record(vrt_ctx* c, int kind, hipEvent_t* a, hipEvent_t* b) {
     HIP_TRY(hipEventCreate(b));
     c->pending.push_back(EventPair{*a, *b, kind});
     return VRT_OK;
+}
+
+// Second copies, streams and events for overlapped launches; false (and never tried again) if they cannot be had.
+static bool ensure_overlap(vrt_ctx* c) {
+    if (c->overlap_ready) return true;
+    if (c->overlap_failed) return false;
+    const size_t n = c->npix;
+    bool ok = true;
+    for (int s = 0; s < 2 && ok; s++)
+        ok = dalloc(&c->alt_multi_d[s], n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->alt_spec_planes[s], n * VRT_MAX_FUSED) == hipSuccess &&
+             dalloc(&c->alt_refl_planes[s], n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->alt_gb_pos[s], n) == hipSuccess &&
+             dalloc(&c->alt_gb_mat[s], n) == hipSuccess && hipStreamCreateWithFlags(&c->rstream[s], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->alt_pool_scratch, pool_scratch_bytes(c->render_blocks)) == hipSuccess;
+    for (int s = 0; s < 3 && ok; s++)
+        ok = hipEventCreateWithFlags(&c->ev_r[s], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_t[s], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); c->overlap_failed = true; return false; }
+    c->overlap_ready = true;
+    return true;
 }
 
 int vrt_accumulate(vrt_ctx* c, int n_samples) {
@@ -381,8 +428,13 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         c->render_blocks = per_cu * c->n_cu;
         c->pooled = pooled;
         if (pooled) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
             if (c->d_pool_scratch) { HIP_TRY(hipFree(c->d_pool_scratch)); c->d_pool_scratch = nullptr; }
             HIP_TRY(hipMalloc((void**)&c->d_pool_scratch, pool_scratch_bytes(c->render_blocks)));
+            if (c->alt_pool_scratch) {
+                HIP_TRY(hipFree(c->alt_pool_scratch)); c->alt_pool_scratch = nullptr;
+                HIP_TRY(hipMalloc((void**)&c->alt_pool_scratch, pool_scratch_bytes(c->render_blocks)));
+            }
         }
     }
     // The samples of one call share camera, jitter and scene; with a still camera at full render scale and ReSTIR
@@ -392,10 +444,41 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
     int max_fused = VRT_MAX_FUSED;
     if (const char* e = getenv("VRT_FUSE")) { int v = atoi(e); if (v >= 1 && v <= VRT_MAX_FUSED) max_fused = v; }
     const bool can_fuse = !restir && c->cam.camera_is_moving == 0 && c->cam.render_scale == 1.0f;
+    // A persistent render launch ends in a tail: the last paths of every wave bounce on at low occupancy (about 0.16 ms
+    // of a 1.5 ms launch at 1080p).  Fused launches of the pooled kernel are therefore OVERLAPPED: launch k+1 goes to
+    // the other of two render streams and writes the other copy of the colour planes / g-buffer while launch k drains
+    // and its temporal pass (main stream, waits for launch k only) runs.  With three copies launch k+3 reuses launch
+    // k's and waits for temporal pass k, so render launches follow each other without a gap and the temporal passes
+    // run beside them.  Results are unchanged; VRT_OVERLAP=0 turns it off.
+    bool may_overlap = c->pooled && can_fuse;
+    if (const char* e = getenv("VRT_OVERLAP")) { if (atoi(e) == 0) may_overlap = false; }
     for (int done = 0; done < n_samples;) {
         int g = (can_fuse && n_samples - done > 1) ? (n_samples - done < max_fused ? n_samples - done : max_fused) : 1;
         if (g > 1 && !c->d_multi_d) {
             if (dalloc(&c->d_multi_d, c->npix * VRT_MAX_FUSED) != hipSuccess) { (void)hipGetLastError(); c->d_multi_d = nullptr; g = 1; }  // no memory: one launch per sample
+        }
+        const bool overlapped = may_overlap && g > 1 && ensure_overlap(c);
+        const int set = overlapped ? (int)(c->pipe_seq % 3u) : 0;
+        const int lane_of = (int)(c->pipe_seq & 1u);  // which render stream (and pool scratch): consecutive launches alternate
+        hipStream_t rs = overlapped ? c->rstream[lane_of] : c->stream;
+        if (overlapped) {
+            if (c->main_dirty) {  // uploads / prepare / sky kernels queued on the main stream come first
+                HIP_TRY(hipEventRecord(c->ev_main, c->stream));
+                HIP_TRY(hipStreamWaitEvent(c->rstream[0], c->ev_main, 0));
+                HIP_TRY(hipStreamWaitEvent(c->rstream[1], c->ev_main, 0));
+                c->main_dirty = false;
+            }
+            if (c->ev_t_valid[set]) HIP_TRY(hipStreamWaitEvent(rs, c->ev_t[set], 0));  // the pass that last read this copy
+        } else if (c->last_set != 0) {
+            // back to the single copy: whoever reads pixels this launch does not write (moving camera at half render
+            // scale) expects the last sample of the last launch in the canonical buffers
+            const size_t last = (size_t)(VRT_MAX_FUSED - 1) * c->npix;
+            const int a = c->last_set - 1;
+            HIP_TRY(hipMemcpyAsync(c->d_color_s, c->alt_spec_planes[a] + last, c->npix * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_gb_refl, c->alt_refl_planes[a] + last, c->npix * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_gb_pos, c->alt_gb_pos[a], c->npix * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_gb_mat, c->alt_gb_mat[a], c->npix * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+            c->last_set = 0;
         }
         if (c->pending.size() > 192) resolve_events(c);
         FrameParams fp = make_frame_params(c);
@@ -406,19 +489,24 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         // specular colour and raw reflection depth: VRT_MAX_FUSED planes each, the LAST plane being the buffer the
         // reference knows (color_buffer_specular, gbuff_depth_reflection); a fused launch ends on it, so whatever
         // later reads stale pixels (moving camera at half render scale) finds the last sample there, as in the reference
-        out.color_d = g > 1 ? c->d_multi_d : rt;
-        out.color_s = c->d_color_s - (size_t)(g - 1) * c->npix;
-        out.gb_refl_depth = c->d_gb_refl - (size_t)(g - 1) * c->npix;
+        const size_t last_plane = (size_t)(VRT_MAX_FUSED - 1) * c->npix;
+        out.color_d = g > 1 ? (set ? c->alt_multi_d[set - 1] : c->d_multi_d) : rt;
+        out.color_s = (set ? c->alt_spec_planes[set - 1] + last_plane : c->d_color_s) - (size_t)(g - 1) * c->npix;
+        out.gb_refl_depth = (set ? c->alt_refl_planes[set - 1] + last_plane : c->d_gb_refl) - (size_t)(g - 1) * c->npix;
         out.sample_stride = g > 1 ? (int)c->npix : 0;
         out.gb_normal = c->d_gb_normal[c->cur]; out.gb_depth = c->d_gb_depth[c->cur];
-        out.gb_position = c->d_gb_pos; out.gb_mat = c->d_gb_mat;
+        out.gb_position = set ? c->alt_gb_pos[set - 1] : c->d_gb_pos; out.gb_mat = set ? c->alt_gb_mat[set - 1] : c->d_gb_mat;
         out.reservoir = c->d_res[0];
         hipEvent_t a, b;
         if (record(c, 0, &a, &b) != VRT_OK) return VRT_E_DEVICE;
-        HIP_TRY(hipEventRecord(a, c->stream));
-        if (c->pooled) HIP_TRY(launch_render_pool(c->stream, instr, c->render_blocks, fp, sc, out, c->d_work, c->launch_seq++, g, c->d_pool_scratch));
-        else HIP_TRY(launch_render(c->stream, restir, instr, c->render_blocks, fp, sc, out, c->d_work, c->launch_seq++, g));
-        HIP_TRY(hipEventRecord(b, c->stream));
+        HIP_TRY(hipEventRecord(a, rs));
+        if (c->pooled) HIP_TRY(launch_render_pool(rs, instr, c->render_blocks, fp, sc, out, c->d_work, c->launch_seq++, g, (overlapped && lane_of) ? c->alt_pool_scratch : c->d_pool_scratch));
+        else HIP_TRY(launch_render(rs, restir, instr, c->render_blocks, fp, sc, out, c->d_work, c->launch_seq++, g));
+        HIP_TRY(hipEventRecord(b, rs));
+        if (overlapped) {
+            HIP_TRY(hipEventRecord(c->ev_r[set], rs));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_r[set], 0));
+        }
         const f3* cd = out.color_d;
         const f3* cs = out.color_s;
         if (restir) {
@@ -440,17 +528,26 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         tb.gb_refl_raw = out.gb_refl_depth; tb.gb_refl_filtered = c->d_gb_refl_f;
         tb.hist_d_in = c->d_hist_d[c->hist_in]; tb.hist_d_out = c->d_hist_d[c->hist_in ^ 1];
         tb.hist_s_in = c->d_hist_s[c->hist_in]; tb.hist_s_out = c->d_hist_s[c->hist_in ^ 1];
-        tb.prev_normal = c->d_gb_normal[c->cur ^ 1]; tb.prev_depth = c->d_gb_depth[c->cur ^ 1];
+        tb.prev_normal = c->d_gb_normal[c->prev_gb]; tb.prev_depth = c->d_gb_depth[c->prev_gb];
         tb.hdr = hdr;
         tb.sample_stride = out.sample_stride;
         tb.prev_view = c->prev_view; tb.prev_proj = c->prev_proj;
         if (record(c, 1, &a, &b) != VRT_OK) return VRT_E_DEVICE;
         HIP_TRY(hipEventRecord(a, c->stream));
-        HIP_TRY(launch_temporal(c->stream, fp, tb, c->own0, c->own1, g));
+        HIP_TRY(launch_temporal(c->stream, fp, tb, c->own0, c->own1, g, overlapped));
         HIP_TRY(hipEventRecord(b, c->stream));
         // pathtracer.py:1298-1303 copy loop == pointer swaps
+        if (overlapped) {
+            HIP_TRY(hipEventRecord(c->ev_t[set], c->stream));
+            c->ev_t_valid[set] = true;
+            c->pipe_seq += 1;
+        } else if (c->overlap_ready) {  // this pass used copy 0 and the single-copy buffers: later overlapped launches wait for it
+            for (int s = 0; s < 3; s++) { HIP_TRY(hipEventRecord(c->ev_t[s], c->stream)); c->ev_t_valid[s] = true; }
+        }
+        c->last_set = set;
         c->hist_in ^= 1;
-        c->cur ^= 1;
+        c->prev_gb = c->cur;
+        c->cur = (c->cur + 1) % 4;
         c->cidx ^= 1;
         c->frame += (uint32_t)g;
         c->stats.path_samples += (uint64_t)g * (uint64_t)c->cfg.width * (uint64_t)(c->own1 - c->own0);
@@ -478,7 +575,7 @@ int vrt_end_frame(vrt_ctx* c) {
 int vrt_sync(vrt_ctx* c) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // every render launch on the render streams has its temporal pass here
     return VRT_OK;
 }
 
@@ -519,6 +616,8 @@ int vrt_set_stream(vrt_ctx* c, void* hip_stream) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     resolve_events(c);
+    c->ev_t_valid[0] = c->ev_t_valid[1] = c->ev_t_valid[2] = false;  // everything recorded on the old stream has completed
+    c->main_dirty = true;
     if (c->owns_stream && c->stream) hipStreamDestroy(c->stream);
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->owns_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->owns_stream = true; }
@@ -534,12 +633,12 @@ int vrt_fetch_ldr(vrt_ctx* c, float* out) {
 }
 int vrt_fetch_buffer(vrt_ctx* c, int which, void* out) {
     if (!c || !out) return fail(VRT_E_INVALID, "null argument");
-    const int last = c->cur ^ 1;  // g-buffer written by the most recent accumulate
+    const int last = c->prev_gb;  // g-buffer written by the most recent accumulate
     switch (which) {
         case VRT_BUF_GBUF_DEPTH: return fetch_rows(c, c->d_gb_depth[last], 4, out);
         case VRT_BUF_GBUF_NORMAL: return fetch_rows(c, c->d_gb_normal[last], 4, out);
-        case VRT_BUF_GBUF_POSITION: return fetch_rows(c, c->d_gb_pos, 12, out);
-        case VRT_BUF_GBUF_MAT: return fetch_rows(c, c->d_gb_mat, 4, out);
+        case VRT_BUF_GBUF_POSITION: return fetch_rows(c, c->last_set ? c->alt_gb_pos[c->last_set - 1] : c->d_gb_pos, 12, out);
+        case VRT_BUF_GBUF_MAT: return fetch_rows(c, c->last_set ? c->alt_gb_mat[c->last_set - 1] : c->d_gb_mat, 4, out);
         case VRT_BUF_GBUF_REFL_DEPTH: return fetch_rows(c, c->d_gb_refl_f, 4, out);
         case VRT_BUF_HISTORY_DIFFUSE: return fetch_rows(c, c->d_hist_d[c->hist_in], 16, out);
         case VRT_BUF_HISTORY_SPECULAR: return fetch_rows(c, c->d_hist_s[c->hist_in], 16, out);

@@ -470,6 +470,18 @@ __global__ __launch_bounds__(256) void k_temporal(FrameParams fp, TemporalBuffer
     const int v = r0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (u < fp.W && v < r1) temporal_pixel(fp, tb, u, v, n_samples);
 }
+// The same pass in 48 registers.  Two pooled render waves per SIMD (232 VGPR each as allocated) leave 48 of the 512:
+// held to that, a temporal pass runs on the same CUs BESIDE the next render launch instead of waiting for its
+// persistent workgroups to retire (overlapped launches, vrt_api.hip).  Alone it is slower (spills: 0.31 vs 0.19 ms at
+// 1080p); beside a VALU-bound render launch its memory time is free.
+#ifndef VRT_TEMPORAL_ARCH_VGPRS
+#define VRT_TEMPORAL_ARCH_VGPRS 24   // + as many accumulation registers for spills = 48 of the unified file
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(VRT_TEMPORAL_ARCH_VGPRS))) void k_temporal_slim(FrameParams fp, TemporalBuffers tb, int r0, int r1, int n_samples) {
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int v = r0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u < fp.W && v < r1) temporal_pixel(fp, tb, u, v, n_samples);
+}
 __global__ __launch_bounds__(256) void k_tonemap(FrameParams fp, const f3* hdr, f4* ldr, int r0, int r1) {
     const int u = blockIdx.x * 64 + (threadIdx.x & 63);
     const int v = r0 + blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -543,9 +555,10 @@ hipError_t query_render_residency(bool restir, bool instr, int* blocks_per_cu) {
 
 hipError_t launch_render(hipStream_t st, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                          const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples) {
-    // two counters alternate between launches: this launch counts on one and zeroes the other for the next launch
-    unsigned* work_counter = work_counters + (launch_seq & 1u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);  // the fused kernel uses head 0 only
-    unsigned* next_counter = work_counters + ((launch_seq + 1u) & 1u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
+    // four sets of heads rotate: launch k counts on set k % 4 and zeroes set (k + 2) % 4 -- launches k and k + 1 may
+    // overlap (vrt_accumulate), so neither the set in use nor the next one may be touched; set k + 1 was zeroed by launch k - 1
+    unsigned* work_counter = work_counters + (launch_seq & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);  // the fused kernel uses head 0 only
+    unsigned* next_counter = work_counters + ((launch_seq + 2u) & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     dim3 g(n_blocks), b(VRT_RENDER_THREADS);
     // pixels a wave reserves per atomic: whole 8x8 tiles.  One tile keeps the tail short (measured: 192-pixel chunks
     // cost 13 % at 1080p on the sparse scene) and still cuts the atomic rate ~3x against per-refill atomics, which
@@ -569,8 +582,8 @@ hipError_t query_render_pool_residency(bool instr, int* blocks_per_cu) {
 size_t pool_scratch_bytes(int n_blocks) { return (size_t)n_blocks * VRT_POOL_WAVES * VRT_POOL_SLOTS * PC_COUNT * sizeof(uint32_t); }
 hipError_t launch_render_pool(hipStream_t st, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                               const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold) {
-    unsigned* work_counter = work_counters + (launch_seq & 1u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
-    unsigned* next_counter = work_counters + ((launch_seq + 1u) & 1u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
+    unsigned* work_counter = work_counters + (launch_seq & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
+    unsigned* next_counter = work_counters + ((launch_seq + 2u) & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     dim3 g(n_blocks), b(64 * VRT_POOL_WAVES);
     if (instr) hipLaunchKernelGGL((k_render_pool<true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold);
     else hipLaunchKernelGGL((k_render_pool<false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold);
@@ -584,9 +597,10 @@ hipError_t launch_gris(hipStream_t st, bool instr, const FrameParams& fp, const 
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1, int n_samples) {
+hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1, int n_samples, bool slim) {
     dim3 g((fp.W + 63) / 64, (r1 - r0 + 3) / 4), b(256);
-    hipLaunchKernelGGL(k_temporal, g, b, 0, st, fp, tb, r0, r1, n_samples);
+    if (slim) hipLaunchKernelGGL(k_temporal_slim, g, b, 0, st, fp, tb, r0, r1, n_samples);
+    else hipLaunchKernelGGL(k_temporal, g, b, 0, st, fp, tb, r0, r1, n_samples);
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
