@@ -80,6 +80,12 @@ struct vrt_ctx {
     f3* alt_multi_d[2] = {nullptr, nullptr}; f3* alt_spec_planes[2] = {nullptr, nullptr}; float* alt_refl_planes[2] = {nullptr, nullptr};
     f3* alt_gb_pos[2] = {nullptr, nullptr}; uint32_t* alt_gb_mat[2] = {nullptr, nullptr};
     uint32_t* alt_pool_scratch = nullptr;  // the second render stream's scratch
+    // A render launch queued behind another on the other render stream would be dispatched at once and sit in the
+    // queue until workgroups retire -- which the profiler and the events count as its run time.  Instead the kernel
+    // raises this word (HSA signal memory) to launch_seq + 1 when it starts to drain, and the next launch's stream
+    // waits for that value (hipStreamWaitValue32) before the dispatch.
+    uint32_t* drain_signal = nullptr;
+    bool drain_signalled = false;  // the most recent render launch was given the signal
     hipStream_t rstream[2] = {nullptr, nullptr};
     hipEvent_t ev_r[3] = {nullptr, nullptr, nullptr}, ev_t[3] = {nullptr, nullptr, nullptr}, ev_main = nullptr;
     bool ev_t_valid[3] = {false, false, false};
@@ -271,6 +277,7 @@ void vrt_destroy(vrt_ctx* c) {
     }
     for (int s = 0; s < 2; s++) if (c->rstream[s]) hipStreamDestroy(c->rstream[s]);
     if (c->ev_main) hipEventDestroy(c->ev_main);
+    if (c->drain_signal) hipFree(c->drain_signal);
     void* ptrs[] = {c->alt_multi_d[0], c->alt_spec_planes[0], c->alt_refl_planes[0], c->alt_gb_pos[0], c->alt_gb_mat[0],
                     c->alt_multi_d[1], c->alt_spec_planes[1], c->alt_refl_planes[1], c->alt_gb_pos[1], c->alt_gb_mat[1],
                     c->alt_pool_scratch, c->d_gb_normal[2], c->d_gb_depth[2], c->d_gb_normal[3], c->d_gb_depth[3],
@@ -399,6 +406,15 @@ static bool ensure_overlap(vrt_ctx* c) {
         ok = hipEventCreateWithFlags(&c->ev_r[s], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_t[s], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) == hipSuccess;
+    int can_wait = 0;
+    if (ok && hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, c->device) == hipSuccess && can_wait &&
+        hipExtMallocWithFlags((void**)&c->drain_signal, 8, hipMallocSignalMemory) == hipSuccess) {
+        if (hipStreamWriteValue32(c->stream, c->drain_signal, 0u, 0) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            (void)hipGetLastError(); hipFree(c->drain_signal); c->drain_signal = nullptr;
+        }
+    } else {
+        (void)hipGetLastError(); c->drain_signal = nullptr;  // no stream wait: launches overlap all the same, only queue earlier
+    }
     if (!ok) { (void)hipGetLastError(); c->overlap_failed = true; return false; }
     c->overlap_ready = true;
     return true;
@@ -469,6 +485,8 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
                 c->main_dirty = false;
             }
             if (c->ev_t_valid[set]) HIP_TRY(hipStreamWaitEvent(rs, c->ev_t[set], 0));  // the pass that last read this copy
+            if (c->drain_signal && c->drain_signalled)  // dispatch when the launch before this one starts to drain
+                HIP_TRY(hipStreamWaitValue32(rs, c->drain_signal, c->launch_seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
         } else if (c->last_set != 0) {
             // back to the single copy: whoever reads pixels this launch does not write (moving camera at half render
             // scale) expects the last sample of the last launch in the canonical buffers
@@ -500,8 +518,10 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         hipEvent_t a, b;
         if (record(c, 0, &a, &b) != VRT_OK) return VRT_E_DEVICE;
         HIP_TRY(hipEventRecord(a, rs));
-        if (c->pooled) HIP_TRY(launch_render_pool(rs, instr, c->render_blocks, fp, sc, out, c->d_work, c->launch_seq++, g, (overlapped && lane_of) ? c->alt_pool_scratch : c->d_pool_scratch));
-        else HIP_TRY(launch_render(rs, restir, instr, c->render_blocks, fp, sc, out, c->d_work, c->launch_seq++, g));
+        const unsigned seq = c->launch_seq++;
+        if (c->pooled) HIP_TRY(launch_render_pool(rs, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch : c->d_pool_scratch, c->drain_signal));
+        else HIP_TRY(launch_render(rs, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g));
+        c->drain_signalled = c->pooled && c->drain_signal != nullptr;
         HIP_TRY(hipEventRecord(b, rs));
         if (overlapped) {
             HIP_TRY(hipEventRecord(c->ev_r[set], rs));

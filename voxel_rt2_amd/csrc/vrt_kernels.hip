@@ -143,6 +143,7 @@ __global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_re
     if (threadIdx.x < 8) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
     for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
     if (blockIdx.x == 0 && threadIdx.x < VRT_WORK_HEADS) next_counter[threadIdx.x * VRT_WORK_HEAD_STRIDE] = 0u;  // the next launch's heads (idle during this launch)
+    if (blockIdx.x == 0 && threadIdx.x == 0) next_counter[1] = 0u;  // and its "drain announced" word
     __syncthreads();
     LdsPyramid P;
     P.l0 = sc.pyr.l0; P.l1 = s_l1; P.l2 = s_l2;
@@ -237,7 +238,7 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
 }
 
 template <bool INSTR>
-__global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_render_pool(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold) {
+__global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_render_pool(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value) {
     __shared__ ulonglong2 s_l12[512];
     __shared__ unsigned long long s_l2[8];
     __shared__ unsigned long long s_fine[VRT_POOL_FINE_WORDS];
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
     for (uint32_t i = threadIdx.x; i < n_fine; i += blockDim.x) s_fine[i] = sc.pyr.l0c[i];
     for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
     if (blockIdx.x == 0 && threadIdx.x < VRT_WORK_HEADS) next_counter[threadIdx.x * VRT_WORK_HEAD_STRIDE] = 0u;  // the next launch's heads (idle during this launch)
+    if (blockIdx.x == 0 && threadIdx.x == 0) next_counter[1] = 0u;  // and its "drain announced" word
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* const pool = s_pool[wave];
     uint32_t* const state = s_state[wave];
@@ -402,7 +404,13 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
                 if (r0 >= total || base + (unsigned)take >= r1) {
                     heads_left -= 1;
                     head = (head + 1u) & (VRT_WORK_HEADS - 1u);
-                    if (heads_left == 0) exhausted = true;
+                    if (heads_left == 0) {
+                        exhausted = true;
+                        // the launch starts to drain: tell the stream holding the NEXT launch back until now (vrt_api.hip)
+                        // (the first wave to get here does; word 1 of this launch's head line says whether one has)
+                        if (drain_signal && lane == 0 && atomicExch(work_counter + 1, 1u) == 0u)
+                            __hip_atomic_fetch_max(drain_signal, drain_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
                 }
                 if (base > limit) base = limit;
             }
@@ -581,12 +589,14 @@ hipError_t query_render_pool_residency(bool instr, int* blocks_per_cu) {
 }
 size_t pool_scratch_bytes(int n_blocks) { return (size_t)n_blocks * VRT_POOL_WAVES * VRT_POOL_SLOTS * PC_COUNT * sizeof(uint32_t); }
 hipError_t launch_render_pool(hipStream_t st, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
-                              const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold) {
+                              const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold,
+                              uint32_t* drain_signal) {
     unsigned* work_counter = work_counters + (launch_seq & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     unsigned* next_counter = work_counters + ((launch_seq + 2u) & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     dim3 g(n_blocks), b(64 * VRT_POOL_WAVES);
-    if (instr) hipLaunchKernelGGL((k_render_pool<true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold);
-    else hipLaunchKernelGGL((k_render_pool<false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold);
+    // the signal carries launch_seq + 1 of the latest launch that has begun to drain
+    if (instr) hipLaunchKernelGGL((k_render_pool<true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u);
+    else hipLaunchKernelGGL((k_render_pool<false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u);
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
