@@ -468,6 +468,9 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
     // run beside them.  Results are unchanged; VRT_OVERLAP=0 turns it off.
     bool may_overlap = c->pooled && can_fuse;
     if (const char* e = getenv("VRT_OVERLAP")) { if (atoi(e) == 0) may_overlap = false; }
+    // rocprofv3 --pmc runs one kernel at a time through an intercepted queue, on which the stream-wait packet never
+    // completes (observed: every counter pass hung); counters are per kernel and want isolated launches anyway
+    if (const char* e = getenv("ROCPROF_COUNTER_COLLECTION")) { if (atoi(e) != 0) may_overlap = false; }
     for (int done = 0; done < n_samples;) {
         int g = (can_fuse && n_samples - done > 1) ? (n_samples - done < max_fused ? n_samples - done : max_fused) : 1;
         if (g > 1 && !c->d_multi_d) {
