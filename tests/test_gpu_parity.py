@@ -312,3 +312,59 @@ def test_fused_samples_equal_separate_launches(monkeypatch):
     orc.setup(nofuse, mat, rgb, params)
     nofuse.accumulate(7)
     assert np.array_equal(nofuse.fetch_hdr().view(np.uint32), a.view(np.uint32))
+
+
+def test_overlapped_launches_match_oracle(monkeypatch):
+    """Fused launches of the pooled kernel overlap (three copies of the planes / g-buffer rotating over two render
+    streams).  Seven calls go round every copy more than twice; a moving-camera pass in between
+    forces the fall back to the single copy (and the copy-back of what stale readers expect there).  Every buffer
+    must equal the oracle's after every phase, and the run with VRT_OVERLAP=0."""
+    mat, rgb, params = scenes.scene_sunlit(0)
+    W, H = 192, 112
+    cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=5, seed=21)
+    g, o = gpu_session(cfg), orc.Oracle(cfg)
+    for s in (g, o):
+        orc.setup(s, mat, rgb, params)
+
+    def moving_cam():
+        pos = (0.45, 0.5, 2.0)
+        view, proj = camera.default_matrices(W, H, pos=pos)
+        return host.make_camera(view, proj, pos, jitter_index=2, moving=True, render_scale=0.5, max_accum_frames=50.0)
+
+    def same():
+        assert np.array_equal(g.fetch_hdr().view(np.uint32), o.fetch_hdr().view(np.uint32))
+        for which in (_abi.BUF_GBUF_DEPTH, _abi.BUF_GBUF_NORMAL, _abi.BUF_GBUF_POSITION, _abi.BUF_GBUF_MAT, _abi.BUF_GBUF_REFL_DEPTH,
+                      _abi.BUF_HISTORY_DIFFUSE, _abi.BUF_HISTORY_SPECULAR):
+            assert np.array_equal(g.fetch_buffer(which).view(np.uint8), o.fetch_buffer(which).view(np.uint8)), which
+
+    for k in range(7):
+        for s in (g, o):
+            s.accumulate(4 if k % 3 else 3)
+        if k in (0, 3, 6):
+            same()
+    # a moving-camera frame at half render scale reads pixels the launch does not write, then static frames again
+    for s in (g, o):
+        s.end_frame()
+        s.set_camera(moving_cam())
+        s.accumulate(1)
+    same()
+    for s in (g, o):
+        s.end_frame()
+        s.set_camera(host.default_camera(W, H, jitter_index=3))
+        s.accumulate(4)
+        s.accumulate(4)
+    same()
+    final = g.fetch_hdr().copy()
+    monkeypatch.setenv("VRT_OVERLAP", "0")
+    g2 = gpu_session(cfg)
+    orc.setup(g2, mat, rgb, params)
+    for k in range(7):
+        g2.accumulate(4 if k % 3 else 3)
+    g2.end_frame()
+    g2.set_camera(moving_cam())
+    g2.accumulate(1)
+    g2.end_frame()
+    g2.set_camera(host.default_camera(W, H, jitter_index=3))
+    g2.accumulate(4)
+    g2.accumulate(4)
+    assert np.array_equal(g2.fetch_hdr().view(np.uint32), final.view(np.uint32))
