@@ -1,10 +1,14 @@
 // vrt_kernels.hip -- gfx950 kernels of libvrt_hip.so.
 //
-//   k_pack_grid / k_build_l0 / k_build_l1 / k_build_l2   prepare_data: packed voxel texels and
-//                                                         the bit-brick occupancy pyramid
-//   k_render<RESTIR, INSTR>                               persistent wave64 path tracer
+//   k_pack_grid / k_build_l0 / k_build_coarse / k_build_l0c   prepare_data: packed voxel texels, the bit-brick
+//                                                         occupancy pyramid and its compacted fine level
+//   k_render_pool<INSTR>                                  persistent wave64 path tracer, pooled schedule (vrt_pool.h):
+//                                                         a wave owns 128 path records in LDS and runs them stage by
+//                                                         stage (WALK / SHADE / ESCAPE / BEGIN); default without ReSTIR
+//   k_render<RESTIR, INSTR>                               persistent wave64 path tracer, one path per lane (vrt_path.h)
 //   k_gris                                                ReSTIR spatial reuse
-//   k_temporal                                            fused temporal accumulation -> HDR
+//   k_temporal, k_temporal_slim                           fused temporal accumulation -> HDR (the slim build fits
+//                                                         beside the next render launch, see vrt_api.hip)
 //   k_tonemap                                             LDR presentation
 //
 // k_render is a persistent-thread kernel: the grid is sized to the device's residency, each wave
