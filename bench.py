@@ -120,6 +120,8 @@ def main():
     # tile boundaries so that all ranks carry the same cost -- the sky rows of this scene cost a fraction of the floor rows.
     bounds = split_rows(HEIGHT, world)
     sess = make_session(bounds[rank])
+    user_overlap = os.environ.get("VRT_OVERLAP")
+    os.environ["VRT_OVERLAP"] = "0"  # isolated launches while measuring: an overlapped launch's span includes its neighbours
     for _ in range(2 if world > 1 else 0):
         sess.accumulate(SPP_PER_STEP)
         lib.vrt_reset_stats(C.c_void_p(sess._ctx))
@@ -131,6 +133,10 @@ def main():
         bounds = parallel.rebalance_rows(bounds, [float(t.item()) for t in allc], HEIGHT)
         sess.close()
         sess = make_session(bounds[rank])
+    if user_overlap is None:
+        os.environ.pop("VRT_OVERLAP", None)
+    else:
+        os.environ["VRT_OVERLAP"] = user_overlap
     rows = bounds[rank]
 
     # gather plumbing: equal-sized tiles (padded to the tallest tile), torch owns the staging tensors
