@@ -7,7 +7,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")): sys.path.insert(0, p)
 import numpy as np
 from voxel_rt2_amd import host, scenes, materials, _lib
 from voxel_rt2_amd._session import NativeSession
-NAMES = {0: "path_begin", 1: "DDA loop trip", 2: "surface shading (frame, sun sample)", 10: "BSDF sample", 3: "shadow ray set-up/result",
+NAMES = {0: "path_begin", 1: "DDA loop trip (WALK stage)", 7: "DDA loop trip (raytrace(): fused kernel, inline shadow rays)", 2: "surface shading (frame, sun sample)", 10: "BSDF sample", 3: "shadow ray set-up/result",
          9: "closest ray set-up/result", 11: "pool SHADE stage", 12: "pool ESCAPE stage", 13: "pool BEGIN stage",
          14: "pool WALK stage", 15: "pool WALK refill", 16: "pool WALK hand-over", 17: "pool WALK suspend", 19: "flat descent: fine brick word needed", 18: "flat descent: fine brick word loaded (L2)", 4: "light-sample evaluation", 5: "escape / sky", 6: "path_finish", 8: "g-buffer (depth 0)"}
 lib = _lib.load()

@@ -182,7 +182,7 @@ VRT_DEV void raytrace(const PyrT& P, f3 o, f3 d, TraceOut& r, int& queries) {
             if (hit_distance > far) { hit_distance = DM_INF; break; }
             bool solid;
             int nq;
-            VRT_REGION(1);
+            VRT_REGION(7);
             if constexpr (PyrT::flat_descend) {  // the pyramid type says which descent suits its kernel (see descend_flat)
                 CoarseWords c;
                 coarse_fetch(P, ix, iy, iz, c);
