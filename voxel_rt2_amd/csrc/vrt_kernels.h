@@ -24,7 +24,9 @@
 // used up.  Two sets of heads alternate between launches (a launch zeroes the set the next one will use).
 #define VRT_WORK_HEADS 8
 #define VRT_WORK_HEAD_STRIDE 32    // uints between heads
+#ifndef VRT_POOL_WAVES
 #define VRT_POOL_WAVES 4           // waves (= path pools) per workgroup of the pooled render kernel
+#endif
 #ifndef VRT_POOL_MIN_WAVES
 #define VRT_POOL_MIN_WAVES 2
 #endif
