@@ -41,6 +41,7 @@ struct vrt_ctx {
     int n_cu = 0, render_blocks = 0;
     bool pooled = false;              // render through k_render_pool (vrt_pool.h) instead of k_render
     uint32_t* d_pool_scratch = nullptr;
+    PrimaryRecord* d_prim_cache[2] = {nullptr, nullptr};  // camera-ray records of fused launches (one table per render stream)
     // rows
     int own0 = 0, own1 = 0;   // rows this context produces
     int buf0 = 0, buf1 = 0;   // rows held in the buffers (own + halo)
@@ -278,7 +279,7 @@ void vrt_destroy(vrt_ctx* c) {
     for (int s = 0; s < 2; s++) if (c->rstream[s]) hipStreamDestroy(c->rstream[s]);
     if (c->ev_main) hipEventDestroy(c->ev_main);
     if (c->drain_signal) hipFree(c->drain_signal);
-    void* ptrs[] = {c->alt_multi_d[0], c->alt_spec_planes[0], c->alt_refl_planes[0], c->alt_gb_pos[0], c->alt_gb_mat[0],
+    void* ptrs[] = {c->d_prim_cache[0], c->d_prim_cache[1], c->alt_multi_d[0], c->alt_spec_planes[0], c->alt_refl_planes[0], c->alt_gb_pos[0], c->alt_gb_mat[0],
                     c->alt_multi_d[1], c->alt_spec_planes[1], c->alt_refl_planes[1], c->alt_gb_pos[1], c->alt_gb_mat[1],
                     c->alt_pool_scratch, c->d_gb_normal[2], c->d_gb_depth[2], c->d_gb_normal[3], c->d_gb_depth[3],
                     c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l0c, c->d_l0c_base, c->d_mats, c->d_counters, c->d_work, c->d_sky_scat,
@@ -522,7 +523,13 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         if (record(c, 0, &a, &b) != VRT_OK) return VRT_E_DEVICE;
         HIP_TRY(hipEventRecord(a, rs));
         const unsigned seq = c->launch_seq++;
-        if (c->pooled) HIP_TRY(launch_render_pool(rs, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch : c->d_pool_scratch, c->drain_signal));
+        PrimaryRecord* prim = nullptr;  // fused samples share their camera rays through this table (vrt_pool.h)
+        if (c->pooled && g > 1) {
+            const int which = (overlapped && lane_of) ? 1 : 0;
+            if (!c->d_prim_cache[which] && dalloc(&c->d_prim_cache[which], c->npix) != hipSuccess) { (void)hipGetLastError(); c->d_prim_cache[which] = nullptr; }
+            prim = c->d_prim_cache[which];
+        }
+        if (c->pooled) HIP_TRY(launch_render_pool(rs, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch : c->d_pool_scratch, c->drain_signal, prim));
         else HIP_TRY(launch_render(rs, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g));
         c->drain_signalled = c->pooled && c->drain_signal != nullptr;
         HIP_TRY(hipEventRecord(b, rs));

@@ -43,7 +43,8 @@ hipError_t query_render_pool_residency(bool instr, int* blocks_per_cu);
 size_t pool_scratch_bytes(int n_blocks);
 hipError_t launch_render_pool(hipStream_t st, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                               const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold,
-                              uint32_t* drain_signal);  // signal memory (or null): receives launch_seq + 1 when the launch starts to drain
+                              uint32_t* drain_signal,   // signal memory (or null): receives launch_seq + 1 when the launch starts to drain
+                              PrimaryRecord* prim_cache);       // per-pixel camera-ray records shared by the fused samples (or null), npix entries
 hipError_t launch_gris(hipStream_t st, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1);
 hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1, int n_samples,
                            bool slim);  // slim: the 48-register build that fits beside two pooled render waves per SIMD

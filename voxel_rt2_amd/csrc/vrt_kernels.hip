@@ -242,7 +242,12 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
 }
 
 template <bool INSTR>
-__global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_render_pool(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value) {
+// 232 registers per wave (the attribute counts half of the unified file): two waves per SIMD then leave the 48 that
+// k_temporal_slim runs in beside them; the allocator would otherwise take a few more and lose that.
+#ifndef VRT_POOL_HALF_VGPRS
+#define VRT_POOL_HALF_VGPRS 116
+#endif
+__global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(VRT_POOL_HALF_VGPRS))) void k_render_pool(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
     __shared__ ulonglong2 s_l12[512];
     __shared__ unsigned long long s_l2[8];
     __shared__ unsigned long long s_fine[VRT_POOL_FINE_WORDS];
@@ -285,7 +290,11 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
     stats_zero(ts);
     bool exhausted = false;  // wave-uniform
     // items are split into VRT_WORK_HEADS contiguous ranges of whole tiles; this wave starts on its XCD's range
-    const unsigned range = ((total / 64u + VRT_WORK_HEADS - 1u) / VRT_WORK_HEADS) * 64u;
+    // a range is a whole number of tiles with all their samples; inside it items run sample-major (all tiles' sample 0,
+    // then all tiles' sample 1, ...) so that the camera-ray records of sample 0 are there when the others begin
+    const unsigned tiles_per_range = ((unsigned)(tiles_x * tiles_y) + VRT_WORK_HEADS - 1u) / VRT_WORK_HEADS;
+    const unsigned range = tiles_per_range * 64u * (unsigned)n_samples;
+    const uint32_t prim_tag = drain_value;  // launch_seq + 1: unique per launch, never 0
     unsigned head = blockIdx.x & (VRT_WORK_HEADS - 1u);  // workgroups go round-robin over the 8 XCDs
     int heads_left = VRT_WORK_HEADS;
 
@@ -358,6 +367,15 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
                     VRT_REGION(16);
                     walk_store(s, w);
                     state[slot] = (uint32_t)slot_state_after_walk(w.t, s.f(PF_FLOOR_T));
+                    if (!INSTR && prim_cache) {  // the camera ray of a pixel's sample 0: leave its record for the other samples
+                        const uint32_t ids = s.u(PF_IDS);
+                        if ((ids >> 24) == 0u) {  // depth 0, sample 0
+                            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                            const PrimaryRecord r = primary_record(s, prim_tag);
+                            const u32x4 r4 = {r.x, r.y, r.z, r.w};  // ONE 16-byte store: a reader sees the tag with its record or neither
+                            *(u32x4*)&prim_cache[((int)((ids >> 12) & 0xfffu) - fp.row0) * fp.W + (int)(ids & 0xfffu)] = r4;
+                        }
+                    }
                     ts.iters += (unsigned)(w.iters - iters0);
                     ended = false;
                 }
@@ -397,6 +415,7 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
         } else {
             const int take = n < 64 ? n : 64;
             unsigned base = 0u, limit = 0u;  // items [base, limit) go to lanes 0.. of this BEGIN
+            unsigned range0 = 0u, per_sample = 1u;  // first item of the range they belong to, items per sample in it
             if (stage == SLOT_EMPTY) {
                 // pull from the current head; a used-up range sends the wave on to the next head (and this BEGIN
                 // hands out nothing: the census runs again)
@@ -406,6 +425,8 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
                 const unsigned r0 = head * range, r1 = (r0 + range < total) ? r0 + range : total;
                 base = r0 + got;
                 limit = (base + (unsigned)take < r1) ? base + (unsigned)take : r1;
+                range0 = r0;
+                per_sample = (r1 > r0) ? (r1 - r0) / (unsigned)n_samples : 1u;
                 if (r0 >= total || base + (unsigned)take >= r1) {
                     heads_left -= 1;
                     head = (head + 1u) & (VRT_WORK_HEADS - 1u);
@@ -434,13 +455,24 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) void k_ren
                     VRT_REGION(13);
                     const unsigned my = base + (unsigned)lane;
                     if (my < limit) {
-                        const unsigned group = my >> 6, in = my & 63u;
-                        const unsigned tile = group / (unsigned)n_samples;
-                        const int sample = (int)(group % (unsigned)n_samples);
+                        const unsigned j = my - range0;  // sample-major inside the range (n_samples <= 4)
+                        const int sample = (int)(j >= per_sample) + (int)(j >= 2u * per_sample) + (int)(j >= 3u * per_sample);
+                        const unsigned rem = j - (unsigned)sample * per_sample;
+                        const unsigned tile = range0 / (64u * (unsigned)n_samples) + (rem >> 6), in = rem & 63u;
                         const int u = (int)(tile % (unsigned)tiles_x) * 8 + (int)(in & 7u);
                         const int v = fp.row0 + (int)(tile / (unsigned)tiles_x) * 8 + (int)(in >> 3);
-                        if (u < fp.W && v < fp.row1 && !outside_render_area(fp, (float)u, (float)v))
-                            state[slot] = (uint32_t)pool_begin(fp, s, u, v, sample, ts);
+                        if (u < fp.W && v < fp.row1 && !outside_render_area(fp, (float)u, (float)v)) {
+                            bool known = false;
+                            PrimaryRecord rec;
+                            rec.x = rec.y = rec.z = rec.w = 0u;
+                            if (!INSTR && prim_cache && sample > 0) {
+                                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                                const u32x4 r4 = __builtin_nontemporal_load((const u32x4*)&prim_cache[(v - fp.row0) * fp.W + u]);  // one 16-byte load past L1: another CU wrote it
+                                rec.x = r4.x; rec.y = r4.y; rec.z = r4.z; rec.w = r4.w;
+                                known = rec.w == prim_tag;
+                            }
+                            state[slot] = (uint32_t)(known ? pool_begin_known(fp, s, u, v, sample, rec) : pool_begin(fp, s, u, v, sample, ts));
+                        }
                     }
                 }
             }
@@ -491,6 +523,9 @@ __global__ __launch_bounds__(256) void k_temporal(FrameParams fp, TemporalBuffer
 #define VRT_TEMPORAL_ARCH_VGPRS 24   // + as many accumulation registers for spills = 48 of the unified file
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(VRT_TEMPORAL_ARCH_VGPRS))) void k_temporal_slim(FrameParams fp, TemporalBuffers tb, int r0, int r1, int n_samples) {
+    // one of these waves shares a SIMD with two render waves that want every VALU cycle; the pass is short but the
+    // NEXT pass queues behind it, so its waves go first
+    __builtin_amdgcn_s_setprio(3);
     const int u = blockIdx.x * 64 + (threadIdx.x & 63);
     const int v = r0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (u < fp.W && v < r1) temporal_pixel(fp, tb, u, v, n_samples);
@@ -595,13 +630,13 @@ hipError_t query_render_pool_residency(bool instr, int* blocks_per_cu) {
 size_t pool_scratch_bytes(int n_blocks) { return (size_t)n_blocks * VRT_POOL_WAVES * VRT_POOL_SLOTS * PC_COUNT * sizeof(uint32_t); }
 hipError_t launch_render_pool(hipStream_t st, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                               const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold,
-                              uint32_t* drain_signal) {
+                              uint32_t* drain_signal, PrimaryRecord* prim_cache) {
     unsigned* work_counter = work_counters + (launch_seq & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     unsigned* next_counter = work_counters + ((launch_seq + 2u) & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     dim3 g(n_blocks), b(64 * VRT_POOL_WAVES);
     // the signal carries launch_seq + 1 of the latest launch that has begun to drain
-    if (instr) hipLaunchKernelGGL((k_render_pool<true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u);
-    else hipLaunchKernelGGL((k_render_pool<false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u);
+    if (instr) hipLaunchKernelGGL((k_render_pool<true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u, prim_cache);
+    else hipLaunchKernelGGL((k_render_pool<false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u, prim_cache);
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -171,6 +171,28 @@ VRT_DEV int pool_launch_ray(const FrameParams& fp, const SlotRef& s, f3 pos, f3 
     return alive ? SLOT_RAY : slot_state_after_walk(w.t, ft);
 }
 
+// The samples fused into one launch share camera and jitter, so a pixel's camera ray -- three quarters of all DDA
+// steps on the sparse scene -- and its whole closest-hit record are the same for all of them.  The path of sample 0
+// leaves the record (distance, cell, normal code; tagged with the launch) in a per-pixel table when its walk ends;
+// work items are ordered sample-major within a work range, so by the time a pixel's later samples begin, the
+// record is there and they start at SHADE / ESCAPE without setting up or walking a ray.  A missing or stale record
+// (other tag) just means the ray is walked as usual.  Records are written and read as one 16-byte word.
+struct alignas(16) PrimaryRecord { uint32_t x, y, z, w; };  // PF_T, PF_CELL_XY, PF_CELL_Z, launch tag
+VRT_DEV PrimaryRecord primary_record(const SlotRef& s, uint32_t tag) {
+    PrimaryRecord r;
+    r.x = s.u(PF_T); r.y = s.u(PF_CELL_XY); r.z = s.u(PF_CELL_Z); r.w = tag;
+    return r;
+}
+VRT_DEV int pool_begin_known(const FrameParams& fp, const SlotRef& s, int u, int v, int sample, PrimaryRecord rec) {
+    Path<false> p;
+    path_begin(fp, p, u, v, sample);
+    path_store_hot(s, p);
+    const float ft = floor_probe(fp, p.pos, p.d);
+    s.sf(PF_FLOOR_T, ft);
+    s.su(PF_T, rec.x); s.su(PF_CELL_XY, rec.y); s.su(PF_CELL_Z, rec.z); s.su(PF_ITERS, 0u);
+    return slot_state_after_walk(dm_u2f(rec.x), ft);
+}
+
 // BEGIN: work item (u, v, sample) -> camera ray pending.
 VRT_DEV int pool_begin(const FrameParams& fp, const SlotRef& s, int u, int v, int sample, TraceStats& ts) {
     Path<false> p;
