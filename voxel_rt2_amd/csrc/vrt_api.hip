@@ -564,7 +564,7 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         tb.prev_view = c->prev_view; tb.prev_proj = c->prev_proj;
         if (record(c, 1, &a, &b) != VRT_OK) return VRT_E_DEVICE;
         HIP_TRY(hipEventRecord(a, c->stream));
-        HIP_TRY(launch_temporal(c->stream, fp, tb, c->own0, c->own1, g, overlapped));
+        HIP_TRY(launch_temporal(c->stream, fp, tb, c->own0, c->own1, g));
         HIP_TRY(hipEventRecord(b, c->stream));
         // pathtracer.py:1298-1303 copy loop == pointer swaps
         if (overlapped) {

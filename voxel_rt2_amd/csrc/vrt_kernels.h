@@ -46,8 +46,7 @@ hipError_t launch_render_pool(hipStream_t st, bool instr, int n_blocks, const Fr
                               uint32_t* drain_signal,   // signal memory (or null): receives launch_seq + 1 when the launch starts to drain
                               PrimaryRecord* prim_cache);       // per-pixel camera-ray records shared by the fused samples (or null), npix entries
 hipError_t launch_gris(hipStream_t st, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1);
-hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1, int n_samples,
-                           bool slim);  // slim: the 48-register build that fits beside two pooled render waves per SIMD
+hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1, int n_samples);
 hipError_t launch_tonemap(hipStream_t st, const FrameParams& fp, const f3* hdr, f4* ldr, int r0, int r1);
 hipError_t launch_diag_read(hipStream_t st, unsigned long long* out, int reset);  // -DVRT_DIAG_REGIONS builds only
 hipError_t launch_detmath_probe(hipStream_t st, int op, int n, const float* a, const float* b, float* out);

@@ -7,8 +7,8 @@
 //                                                         stage (WALK / SHADE / ESCAPE / BEGIN); default without ReSTIR
 //   k_render<RESTIR, INSTR>                               persistent wave64 path tracer, one path per lane (vrt_path.h)
 //   k_gris                                                ReSTIR spatial reuse
-//   k_temporal, k_temporal_slim                           fused temporal accumulation -> HDR (the slim build fits
-//                                                         beside the next render launch, see vrt_api.hip)
+//   k_temporal                                            fused temporal accumulation -> HDR (sized to run beside
+//                                                         the next render launch, see vrt_api.hip)
 //   k_tonemap                                             LDR presentation
 //
 // k_render is a persistent-thread kernel: the grid is sized to the device's residency, each wave
@@ -242,10 +242,10 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
 }
 
 template <bool INSTR>
-// 232 registers per wave (the attribute counts half of the unified file): two waves per SIMD then leave the 48 that
-// k_temporal_slim runs in beside them; the allocator would otherwise take a few more and lose that.
+// 208 registers per wave (the attribute counts half of the unified file): two waves per SIMD then leave the 96 that
+// k_temporal runs in beside them (see there).  The allocator would take 238; the cap costs 28 bytes of scratch.
 #ifndef VRT_POOL_HALF_VGPRS
-#define VRT_POOL_HALF_VGPRS 116
+#define VRT_POOL_HALF_VGPRS 104
 #endif
 __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(VRT_POOL_HALF_VGPRS))) void k_render_pool(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
     __shared__ ulonglong2 s_l12[512];
@@ -510,22 +510,15 @@ __global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES) void k_gris(FrameParams fp
 }
 
 // ---- temporal accumulation + presentation ------------------------------------------------------
-__global__ __launch_bounds__(256) void k_temporal(FrameParams fp, TemporalBuffers tb, int r0, int r1, int n_samples) {
-    const int u = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int v = r0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (u < fp.W && v < r1) temporal_pixel(fp, tb, u, v, n_samples);
-}
-// The same pass in 48 registers.  Two pooled render waves per SIMD (232 VGPR each as allocated) leave 48 of the 512:
-// held to that, a temporal pass runs on the same CUs BESIDE the next render launch instead of waiting for its
-// persistent workgroups to retire (overlapped launches, vrt_api.hip).  Alone it is slower (spills: 0.31 vs 0.19 ms at
-// 1080p); beside a VALU-bound render launch its memory time is free.
-#ifndef VRT_TEMPORAL_ARCH_VGPRS
-#define VRT_TEMPORAL_ARCH_VGPRS 24   // + as many accumulation registers for spills = 48 of the unified file
+// Register budgets chosen together (overlapped launches, vrt_api.hip): two pooled render waves at 208 registers leave
+// 96 of a SIMD's 512, which is what this kernel is held to, so that a temporal pass runs on the same CUs BESIDE the next
+// render launch instead of waiting for its persistent workgroups to retire.  (A 48-register build beside 232-register
+// render waves was the first version: its spills made it 1.2 ms long beside a launch; this one measured 4 % faster.
+// Raising its waves' priority with s_setprio measured 2.5 % slower.)
+#ifndef VRT_TEMPORAL_HALF_VGPRS
+#define VRT_TEMPORAL_HALF_VGPRS 48   // the attribute counts half of the unified register file
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(VRT_TEMPORAL_ARCH_VGPRS))) void k_temporal_slim(FrameParams fp, TemporalBuffers tb, int r0, int r1, int n_samples) {
-    // one of these waves shares a SIMD with two render waves that want every VALU cycle; the pass is short but the
-    // NEXT pass queues behind it, so its waves go first
-    __builtin_amdgcn_s_setprio(3);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(VRT_TEMPORAL_HALF_VGPRS))) void k_temporal(FrameParams fp, TemporalBuffers tb, int r0, int r1, int n_samples) {
     const int u = blockIdx.x * 64 + (threadIdx.x & 63);
     const int v = r0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (u < fp.W && v < r1) temporal_pixel(fp, tb, u, v, n_samples);
@@ -647,10 +640,9 @@ hipError_t launch_gris(hipStream_t st, bool instr, const FrameParams& fp, const 
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1, int n_samples, bool slim) {
+hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1, int n_samples) {
     dim3 g((fp.W + 63) / 64, (r1 - r0 + 3) / 4), b(256);
-    if (slim) hipLaunchKernelGGL(k_temporal_slim, g, b, 0, st, fp, tb, r0, r1, n_samples);
-    else hipLaunchKernelGGL(k_temporal, g, b, 0, st, fp, tb, r0, r1, n_samples);
+    hipLaunchKernelGGL(k_temporal, g, b, 0, st, fp, tb, r0, r1, n_samples);
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
