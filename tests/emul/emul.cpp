@@ -170,6 +170,8 @@ static void render_all(Emu* c, const FrameParams& fp, const SceneData& sc, const
 static void render_all_pool(Emu* c, const FrameParams& fp, const SceneData& sc, const PixelBuffers& out) {
     GlobalPyramid P;
     P.p = sc.pyr;
+    // the launcher's choice of kernel variant (vrt_kernels.hip, launch_render_pool)
+    const bool black_sun = !((fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f);
     for (int v = fp.row0; v < fp.row1; v++)
         for (int u = 0; u < fp.W; u++) {
             if (outside_render_area(fp, (float)u, (float)v)) continue;
@@ -195,9 +197,10 @@ static void render_all_pool(Emu* c, const FrameParams& fp, const SceneData& sc, 
                     walk_store(s, w);
                     st = slot_state_after_walk(w.t, s.f(PF_FLOOR_T));
                 } else if (st == SLOT_SHADE) {
-                    st = pool_shade<HIT_SOMETHING>(fp, sc, P, out, s, cold, c->ts);
+                    st = black_sun ? pool_shade<HIT_SOMETHING, true>(fp, sc, P, out, s, cold, c->ts)
+                                   : pool_shade<HIT_SOMETHING, false>(fp, sc, P, out, s, cold, c->ts);
                 } else {
-                    st = pool_shade<HIT_NOTHING>(fp, sc, P, out, s, cold, c->ts);
+                    st = pool_shade<HIT_NOTHING, false>(fp, sc, P, out, s, cold, c->ts);
                 }
             }
         }

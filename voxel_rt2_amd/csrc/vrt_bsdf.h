@@ -23,14 +23,17 @@ VRT_DEV void ortho_basis(f3 n, f3& x, f3& y) {  // :32-37
     y = norm3(cross3(n, h));
     x = cross3(n, y);
 }
-VRT_DEV f3 cone_dir(float cos_max, f3 n, f3 bx, f3 by, dm_rng& rng) {  // :44-59 with the basis hoisted
-    float u0 = dm_rng_f32(&rng), u1 = dm_rng_f32(&rng);
+VRT_DEV f3 cone_dir_from(float cos_max, f3 n, f3 bx, f3 by, float u0, float u1) {  // :44-59 after its two draws, basis hoisted
     float ct = (1.0f - u0) + u0 * cos_max;
     float st = dm_sqrt(1.0f - ct * ct);
     float s, c;
     dm_sincos(DM_TWO_PI * u1, &s, &c);
     f3 v = mk3(st * c, st * s, ct);
     return mk3(bx.x * v.x + by.x * v.y + n.x * v.z, bx.y * v.x + by.y * v.y + n.y * v.z, bx.z * v.x + by.z * v.y + n.z * v.z);
+}
+VRT_DEV f3 cone_dir(float cos_max, f3 n, f3 bx, f3 by, dm_rng& rng) {
+    const float u0 = dm_rng_f32(&rng), u1 = dm_rng_f32(&rng);
+    return cone_dir_from(cos_max, n, bx, by, u0, u1);
 }
 VRT_DEV float cone_pdf(float cos_max, float cos_theta) {  // :61-63
     return (cos_theta >= cos_max) ? 1.0f / (DM_TWO_PI * (1.0f - cos_max)) : 0.0f;

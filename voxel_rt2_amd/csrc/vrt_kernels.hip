@@ -241,7 +241,7 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-template <bool INSTR>
+template <bool INSTR, bool BLACK_SUN>
 // 208 registers per wave (the attribute counts half of the unified file): two waves per SIMD then leave the 96 that
 // k_temporal runs in beside them (see there).  The allocator would take 238; the cap costs 28 bytes of scratch.
 #ifndef VRT_POOL_HALF_VGPRS
@@ -447,10 +447,10 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) __attribut
                 uint32_t* const cold_line = cold_wave + slot * PC_COUNT;
                 if (stage == SLOT_SHADE) {
                     VRT_REGION(11);
-                    state[slot] = (uint32_t)pool_shade<HIT_SOMETHING>(fp, scl, P, out, s, cold_line, ts);
+                    state[slot] = (uint32_t)pool_shade<HIT_SOMETHING, BLACK_SUN>(fp, scl, P, out, s, cold_line, ts);
                 } else if (stage == SLOT_ESCAPE) {
                     VRT_REGION(12);
-                    state[slot] = (uint32_t)pool_shade<HIT_NOTHING>(fp, scl, P, out, s, cold_line, ts);
+                    state[slot] = (uint32_t)pool_shade<HIT_NOTHING, false>(fp, scl, P, out, s, cold_line, ts);
                 } else {
                     VRT_REGION(13);
                     const unsigned my = base + (unsigned)lane;
@@ -617,8 +617,8 @@ hipError_t launch_render(hipStream_t st, bool restir, bool instr, int n_blocks, 
     return hipSuccess;
 }
 hipError_t query_render_pool_residency(bool instr, int* blocks_per_cu) {
-    return instr ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool<true>, 64 * VRT_POOL_WAVES, 0)
-                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool<false>, 64 * VRT_POOL_WAVES, 0);
+    return instr ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool<true, false>, 64 * VRT_POOL_WAVES, 0)
+                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool<false, false>, 64 * VRT_POOL_WAVES, 0);
 }
 size_t pool_scratch_bytes(int n_blocks) { return (size_t)n_blocks * VRT_POOL_WAVES * VRT_POOL_SLOTS * PC_COUNT * sizeof(uint32_t); }
 hipError_t launch_render_pool(hipStream_t st, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
@@ -628,8 +628,12 @@ hipError_t launch_render_pool(hipStream_t st, bool instr, int n_blocks, const Fr
     unsigned* next_counter = work_counters + ((launch_seq + 2u) & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     dim3 g(n_blocks), b(64 * VRT_POOL_WAVES);
     // the signal carries launch_seq + 1 of the latest launch that has begun to drain
-    if (instr) hipLaunchKernelGGL((k_render_pool<true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u, prim_cache);
-    else hipLaunchKernelGGL((k_render_pool<false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u, prim_cache);
+    // the black-sun variant (scene.py's default light) compiles the light sample out of the shading stage
+    const bool black_sun = !((fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f);
+#define VRT_LAUNCH_POOL(I, B) hipLaunchKernelGGL((k_render_pool<I, B>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u, prim_cache)
+    if (instr) { if (black_sun) VRT_LAUNCH_POOL(true, true); else VRT_LAUNCH_POOL(true, false); }
+    else { if (black_sun) VRT_LAUNCH_POOL(false, true); else VRT_LAUNCH_POOL(false, false); }
+#undef VRT_LAUNCH_POOL
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }

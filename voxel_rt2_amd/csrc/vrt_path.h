@@ -183,7 +183,11 @@ VRT_DEV void path_begin(const FrameParams& fp, Path<RESTIR>& p, int u, int v, in
 enum { HIT_ANY = 0, HIT_SOMETHING = 1, HIT_NOTHING = 2 };
 
 // One iteration of pathtracer.py:396-525 after its closest-hit query `h`.  Returns true when the path is over.
-template <bool RESTIR, int KIND, class PyrT>
+// BLACK_SUN: the caller knows (and the launch parameters say) that the sun does not emit -- scene.py's default, which
+// example1.py never changes.  Then nothing can use the light sample except case (b) below, and the compiler drops
+// the sun direction (a basis, a sincos, a square root), the light-sample evaluation and what feeds them from the
+// common path; the two draws of the cone sampler are still made, so every later draw keeps its place in the stream.
+template <bool RESTIR, int KIND, bool BLACK_SUN = false, class PyrT>
 VRT_DEV bool path_shade(const FrameParams& fp, const SceneData& sc, const PyrT& P, const PixelBuffers& out, int local_idx,
                         Path<RESTIR>& p, const Hit& h, TraceStats& ts) {
     const int depth = p.depth;
@@ -231,11 +235,17 @@ VRT_DEV bool path_shade(const FrameParams& fp, const SceneData& sc, const PyrT& 
         //   (b) the sampled bounce direction lies inside the sun cone, where NEE_visible enters its MIS weight (:490-491).
         // With a black sun (scene.py:127's default, e.g. example1.py) the light-sample terms are exact zeros
         // (firefly() maps a NaN product to 0), so the ray and the BSDF evaluation behind it are skipped.
-        f3 lx, ly;
-        ortho_basis(fp.light_dir, lx, ly);
-        const f3 ldir = cone_dir(fp.light_cos_max, fp.light_dir, lx, ly, p.rng);
-        const float ndl = dot3(ldir, h.normal);
-        const bool light_on = (fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f;
+        const float lu0 = dm_rng_f32(&p.rng), lu1 = dm_rng_f32(&p.rng);  // cone_dir's two draws
+        f3 ldir = mk3(0.0f);
+        float ndl = 0.0f;
+        if constexpr (!(BLACK_SUN && !RESTIR)) {
+            f3 lx, ly;
+            ortho_basis(fp.light_dir, lx, ly);
+            ldir = cone_dir_from(fp.light_cos_max, fp.light_dir, lx, ly, lu0, lu1);
+            ndl = dot3(ldir, h.normal);
+        }
+        const bool light_on = !(BLACK_SUN && !RESTIR) &&
+                              (fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f;
         if constexpr (RESTIR) {
             if (depth == 0) { p.rs.first_light_bsdf_pdf = pdf_all(s, ldir); p.rs.first_light_dir = ldir; }
         }
@@ -247,6 +257,14 @@ VRT_DEV bool path_shade(const FrameParams& fp, const SceneData& sc, const PyrT& 
             VRT_REGION(10);
             next_d = sample_bsdf(s, p.rng, brdf, pdf, lobe);
             bounce_light_pdf = cone_pdf(fp.light_cos_max, dot3(fp.light_dir, next_d));
+        }
+        if constexpr (BLACK_SUN && !RESTIR) {
+            if (depth > 0 && bounce_light_pdf > 0.0f) {  // case (b): the only use of the sun direction under a black sun
+                f3 lx, ly;
+                ortho_basis(fp.light_dir, lx, ly);
+                ldir = cone_dir_from(fp.light_cos_max, fp.light_dir, lx, ly, lu0, lu1);
+                ndl = dot3(ldir, h.normal);
+            }
         }
         float nee_visible = 0.0f;
         if (ndl > 0.0f && (RESTIR || light_on || (depth > 0 && bounce_light_pdf > 0.0f))) {

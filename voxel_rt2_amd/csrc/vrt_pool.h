@@ -203,7 +203,7 @@ VRT_DEV int pool_begin(const FrameParams& fp, const SlotRef& s, int u, int v, in
 
 // SHADE (KIND = HIT_SOMETHING) and ESCAPE (KIND = HIT_NOTHING): rebuild the closest hit from the slot, run the
 // segment, then either set up the bounce ray or finish the path.  Returns the slot's next state.
-template <int KIND, class PyrT>
+template <int KIND, bool BLACK_SUN, class PyrT>
 VRT_DEV int pool_shade(const FrameParams& fp, const SceneData& sc, const PyrT& P, const PixelBuffers& out, const SlotRef& s,
                        uint32_t* cold_line, TraceStats& ts) {
     Path<false> p;
@@ -221,7 +221,7 @@ VRT_DEV int pool_shade(const FrameParams& fp, const SceneData& sc, const PyrT& P
                     normal_decode(b >> 20), (int)s.u(PF_ITERS), tr);
         hit_voxel<false>(fp, sc, world_to_voxel(p.pos), p.d, tr, h, ts);
     }
-    const bool done = path_shade<false, KIND>(fp, sc, P, out, local_idx, p, h, ts);
+    const bool done = path_shade<false, KIND, BLACK_SUN>(fp, sc, P, out, local_idx, p, h, ts);
     if (done) {
         if (depth > 0) path_load_cold(cold_line, p);
         path_finish<false>(fp, sc, out, local_idx, p, ts);
