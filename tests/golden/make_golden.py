@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz with the CPU oracle (oracle/ -- the restatement of the reference path).
+
+These are NOT outputs of the reference: it only runs through the Taichi JIT, which cannot be installed here
+("parity unpinned").  They freeze what the oracle computes today for a few small,
+fixed cases, so that (a) a change to the oracle that alters results is noticed on the CPU and (b) the GPU box
+can check libvrt_hip.so against committed data even without rebuilding the oracle (tests/test_golden.py).
+
+    python tests/golden/make_golden.py        # from the repo root; overwrites the fixtures
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.dirname(HERE)):
+    sys.path.insert(0, p)
+import numpy as np
+import orc
+from voxel_rt2_amd import _abi, camera, host, scenes
+
+BUFS = {"gbuf_depth": _abi.BUF_GBUF_DEPTH, "gbuf_normal": _abi.BUF_GBUF_NORMAL, "gbuf_mat": _abi.BUF_GBUF_MAT,
+        "history_diffuse": _abi.BUF_HISTORY_DIFFUSE, "history_specular": _abi.BUF_HISTORY_SPECULAR}
+
+# name -> (scene, scene seed, W, H, max depth, rng seed, ReSTIR, script); script = list of steps
+CASES = {
+    "s1_64x64_d4": ("s1", 0, 64, 64, 4, 0, False, [("accumulate", 1)]),                       # BASELINE config 1 in small
+    "s1_96x56_d8_fused": ("s1", 0, 96, 56, 8, 5, False, [("accumulate", 4), ("accumulate", 3)]),
+    "sunlit_80x48_d6": ("sunlit", 0, 80, 48, 6, 11, False, [("accumulate", 2), ("accumulate", 4)]),
+    "dense_48x40_d5": ("dense", 12345, 48, 40, 5, 3, False, [("accumulate", 3)]),
+    "sunlit_restir_64x40_d4": ("sunlit", 0, 64, 40, 4, 7, True, [("accumulate", 2)]),
+    "sunlit_moving_72x44_d4": ("sunlit", 0, 72, 44, 4, 9, False, [("accumulate", 2), ("end_frame",), ("move", 0.45), ("accumulate", 1),
+                                                                   ("end_frame",), ("move", 0.5), ("accumulate", 1)]),
+}
+
+
+def run_case(session, case):
+    """Drives any session object (oracle, emulation, GPU) through a case's script."""
+    scene, scene_seed, W, H, depth, seed, restir, script = case
+    mat, rgb, params = scenes.SCENES[scene](scene_seed)
+    params = dict(params, use_physical_sky=0, use_clouds=0)
+    orc.setup(session, mat, rgb, params)
+    k = 1
+    for step in script:
+        if step[0] == "accumulate":
+            session.accumulate(step[1])
+        elif step[0] == "end_frame":
+            session.end_frame()
+        elif step[0] == "move":
+            pos = (step[1], 0.5, 2.0)
+            view, proj = camera.default_matrices(W, H, pos=pos)
+            k += 1
+            session.set_camera(host.make_camera(view, proj, pos, jitter_index=k, moving=True, render_scale=0.5, max_accum_frames=50.0))
+    out = {"hdr": session.fetch_hdr(), "ldr": session.fetch_ldr()}
+    for name, which in BUFS.items():
+        out[name] = session.fetch_buffer(which)
+    return out
+
+
+def config_of(case):
+    scene, scene_seed, W, H, depth, seed, restir, script = case
+    _, _, params = scenes.SCENES[scene](scene_seed)
+    return host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=depth, seed=seed, use_restir=restir)
+
+
+if __name__ == "__main__":
+    for name, case in CASES.items():
+        o = orc.Oracle(config_of(case))
+        out = run_case(o, case)
+        o.close()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, {k: (v.shape, str(v.dtype)) for k, v in out.items()}, os.path.getsize(os.path.join(HERE, name + ".npz")), "bytes")
