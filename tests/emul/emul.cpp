@@ -222,6 +222,10 @@ int emu_accumulate(Emu* c, int n_samples) {
         f3* rt = c->cbuf[c->cidx].data();
         f3* hdr = c->cbuf[c->cidx ^ 1].data();
         out.color_d = rt; out.color_s = c->color_s.data();
+        if (c->cam.render_scale != 1.0f) {  // as vrt_api.hip: a partial pass starts from the last pass's g-buffer
+            c->gb_normal[c->cur] = c->gb_normal[c->cur ^ 1];
+            c->gb_depth[c->cur] = c->gb_depth[c->cur ^ 1];
+        }
         out.gb_normal = c->gb_normal[c->cur].data(); out.gb_depth = c->gb_depth[c->cur].data();
         out.gb_refl_depth = c->gb_refl.data(); out.gb_position = c->gb_pos.data(); out.gb_mat = c->gb_mat.data();
         out.reservoir = c->res[0].data();

@@ -20,6 +20,7 @@ import orc
 from voxel_rt2_amd import _abi, camera, host, scenes
 
 BUFS = {"gbuf_depth": _abi.BUF_GBUF_DEPTH, "gbuf_normal": _abi.BUF_GBUF_NORMAL, "gbuf_mat": _abi.BUF_GBUF_MAT,
+        "gbuf_position": _abi.BUF_GBUF_POSITION, "gbuf_refl_depth": _abi.BUF_GBUF_REFL_DEPTH,
         "history_diffuse": _abi.BUF_HISTORY_DIFFUSE, "history_specular": _abi.BUF_HISTORY_SPECULAR}
 
 # name -> (scene, scene seed, W, H, max depth, rng seed, ReSTIR, script); script = list of steps
@@ -31,6 +32,11 @@ CASES = {
     "sunlit_restir_64x40_d4": ("sunlit", 0, 64, 40, 4, 7, True, [("accumulate", 2)]),
     "sunlit_moving_72x44_d4": ("sunlit", 0, 72, 44, 4, 9, False, [("accumulate", 2), ("end_frame",), ("move", 0.45), ("accumulate", 1),
                                                                    ("end_frame",), ("move", 0.5), ("accumulate", 1)]),
+    # two static frames with different jitter, then a quarter-frame pass: the pixels it leaves out must keep the
+    # g-buffer of the LAST pass (the reference's g-buffer is one array), then static again
+    "s1_jitter_then_moving_64x48_d5": ("s1", 0, 64, 48, 5, 13, False, [("accumulate", 4), ("end_frame",), ("still", 2), ("accumulate", 3),
+                                                                       ("end_frame",), ("move", 0.42), ("accumulate", 1), ("end_frame",),
+                                                                       ("still", 4), ("accumulate", 4)]),
 }
 
 
@@ -46,6 +52,8 @@ def run_case(session, case):
             session.accumulate(step[1])
         elif step[0] == "end_frame":
             session.end_frame()
+        elif step[0] == "still":
+            session.set_camera(host.default_camera(W, H, jitter_index=step[1]))
         elif step[0] == "move":
             pos = (step[1], 0.5, 2.0)
             view, proj = camera.default_matrices(W, H, pos=pos)

@@ -517,6 +517,12 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         out.gb_refl_depth = (set ? c->alt_refl_planes[set - 1] + last_plane : c->d_gb_refl) - (size_t)(g - 1) * c->npix;
         out.sample_stride = g > 1 ? (int)c->npix : 0;
         out.gb_normal = c->d_gb_normal[c->cur]; out.gb_depth = c->d_gb_depth[c->cur];
+        if (c->cam.render_scale != 1.0f) {
+            // a pass that renders part of the frame: the reference's g-buffer is ONE array, so the pixels it leaves out
+            // keep what the last pass wrote -- the rotating copy starts as a copy of the last one
+            HIP_TRY(hipMemcpyAsync(c->d_gb_normal[c->cur], c->d_gb_normal[c->prev_gb], c->npix * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_gb_depth[c->cur], c->d_gb_depth[c->prev_gb], c->npix * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        }
         out.gb_position = set ? c->alt_gb_pos[set - 1] : c->d_gb_pos; out.gb_mat = set ? c->alt_gb_mat[set - 1] : c->d_gb_mat;
         out.reservoir = c->d_res[0];
         hipEvent_t a, b;
