@@ -32,6 +32,8 @@ CASES = {
     "sunlit_restir_64x40_d4": ("sunlit", 0, 64, 40, 4, 7, True, [("accumulate", 2)]),
     "sunlit_moving_72x44_d4": ("sunlit", 0, 72, 44, 4, 9, False, [("accumulate", 2), ("end_frame",), ("move", 0.45), ("accumulate", 1),
                                                                    ("end_frame",), ("move", 0.5), ("accumulate", 1)]),
+    "sunlit_restir_moving_56x40_d4": ("sunlit", 0, 56, 40, 4, 17, True, [("accumulate", 2), ("end_frame",), ("move", 0.44), ("accumulate", 1),
+                                                                        ("end_frame",), ("still", 3), ("accumulate", 2)]),
     # two static frames with different jitter, then a quarter-frame pass: the pixels it leaves out must keep the
     # g-buffer of the LAST pass (the reference's g-buffer is one array), then static again
     "s1_jitter_then_moving_64x48_d5": ("s1", 0, 64, 48, 5, 13, False, [("accumulate", 4), ("end_frame",), ("still", 2), ("accumulate", 3),

@@ -227,9 +227,12 @@ template <class PyrT>
 VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& P, const GrisBuffers& gb, int u, int v,
                         int pass_id, float max_radius, int max_taps, int pass_total, TraceStats& ts) {
     const int idx = (v - fp.row0) * fp.W + u;
-    if (outside_render_area(fp, (float)u, (float)v)) {  // untouched by the reference: carry the stale values across
+    if (outside_render_area(fp, (float)u, (float)v)) {
+        // Untouched by the reference, whose colour buffers are updated in place.  Diffuse: the input buffer holds the
+        // last HDR value there (it swaps roles with the HDR target every pass): carry it across.  Specular: what the
+        // reference still has there is the LAST PASS'S RESULT OF THIS KERNEL, which is exactly what the output buffer
+        // still holds -- leave it (copying the input would bring back the last render output from before its reuse).
         gb.color_d_out[idx] = gb.color_d_in[idx];
-        gb.color_s_out[idx] = gb.color_s_in[idx];
         return;
     }
     dm_rng rng = dm_rng_init(fp.seed, fp.frame, (uint32_t)(v * fp.W + u), 1u);
