@@ -31,8 +31,10 @@ for k in range(n_cases):
     W, H = int(rng.integers(24, 120)), int(rng.integers(16, 90))
     depth, seed, restir = int(rng.integers(1, 7)), int(rng.integers(0, 1 << 30)), bool(rng.integers(0, 3) == 0)
     mat, rgb, params = scenes.SCENES[scene](int(rng.integers(0, 4)))
-    params = dict(params, use_physical_sky=0, use_clouds=0)
-    cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=depth, seed=seed, use_restir=restir)
+    sky = scene == "s6" and bool(rng.integers(0, 2))  # the physical sky with clouds, tables at 32 x 32 (precomputed by both sides)
+    if not sky: params = dict(params, use_physical_sky=0, use_clouds=0)
+    cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=depth, seed=seed, use_restir=restir,
+                           sky_res=32 if sky else 0)
     script, jitter = [], 1
     for _ in range(int(rng.integers(2, 8))):
         r = int(rng.integers(0, 10))
@@ -50,7 +52,14 @@ for k in range(n_cases):
             else: script.append(("scene", dict(background_color=[float(x) for x in rng.uniform(0, 1, 3)],
                                                light_direction=[float(x) for x in rng.uniform(-1, 1, 3)], light_cone=float(rng.uniform(0.01, 0.6)))))
     o, e = orc.Oracle(cfg, threads=4), second(cfg)
-    for s in (o, e): orc.setup(s, mat, rgb, params)
+    cloud = np.load(os.path.join(ROOT, "voxel_rt2_amd", "data", "cloud_texture.npy")) if sky else None
+    for s in (o, e):
+        orc.setup(s, mat, rgb, params, cloud=cloud if (use_gpu or s is o) else None)
+        if sky and (use_gpu or s is o):
+            s.sky_accumulate_clouds(1)
+            for sl in range(2): s.sky_compute_slice(sl, 2)
+    if sky and not use_gpu:  # the emulation has no precompute kernels: it is handed the oracle's tables
+        e.upload_sky(o.fetch_buffer(_abi.BUF_SKY_SCATTERING), o.fetch_buffer(_abi.BUF_SKY_TRANSMITTANCE))
     ok, where = True, None
     for i, step in enumerate(script):
         for s in (o, e):
@@ -65,13 +74,15 @@ for k in range(n_cases):
                 s.set_scene(host.make_scene_params(**params))
             elif step[0] == "voxels":
                 m2, r2, _ = scenes.SCENES[scene](step[1]); s.upload_voxels(m2, r2); s.prepare()
+                if sky and not use_gpu and s is e:  # prepare() restarts the sky tables (pathtracer.py:322-323): hand the emulation the oracle's
+                    e.upload_sky(o.fetch_buffer(_abi.BUF_SKY_SCATTERING), o.fetch_buffer(_abi.BUF_SKY_TRANSMITTANCE))
         if step[0] == "acc":
             same = np.array_equal(o.fetch_hdr().view(np.uint32), e.fetch_hdr().view(np.uint32))
             diff = [] if same else ["hdr"]
             for which in BUFS:
                 if not np.array_equal(np.ascontiguousarray(o.fetch_buffer(which)).view(np.uint8), np.ascontiguousarray(e.fetch_buffer(which)).view(np.uint8)): diff.append(which)
             if diff and ok: ok, where = False, (i, step, diff)
-    print(f"case {k}: {scene} {W}x{H} depth {depth} seed {seed} restir {restir} script {script}: {'ok' if ok else 'MISMATCH at step %s' % (where,)}", flush=True)
+    print(f"case {k}: {scene}{'+sky' if sky else ''} {W}x{H} depth {depth} seed {seed} restir {restir} script {script}: {'ok' if ok else 'MISMATCH at step %s' % (where,)}", flush=True)
     bad += 0 if ok else 1
     o.close(); e.close()
 print("mismatches:", bad)
