@@ -31,7 +31,21 @@ for k in range(n_cases):
     ok = np.array_equal(g.fetch_hdr().view(np.uint32), o.fetch_hdr().view(np.uint32))
     for which in BUFS:
         ok = ok and np.array_equal(g.fetch_buffer(which).view(np.uint8), o.fetch_buffer(which).view(np.uint8))
-    print(f"case {k}: {scene} {W}x{H} depth {depth} seed {seed} calls {calls}: {'ok' if ok else 'MISMATCH'}", flush=True)
+    # the multi-GPU decomposition: contexts that own a random split of the rows reassemble the same frame
+    full = g.fetch_hdr()
+    cuts = sorted(set([0, H] + [int(x) for x in rng.integers(1, H, size=int(rng.integers(1, 4)))]))
+    parts = np.zeros_like(full)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        cfg_s = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=depth, seed=seed, rows=(a, b))
+        sh = NativeSession(_lib.load(), "vrt_", cfg_s)
+        orc.setup(sh, mat, rgb, params)
+        for n in calls:
+            sh.accumulate(n)
+        parts[a:b] = sh.fetch_hdr()[a:b]
+        sh.close()
+    shards_ok = np.array_equal(full.view(np.uint32), parts.view(np.uint32))
+    ok = ok and shards_ok
+    print(f"case {k}: {scene} {W}x{H} depth {depth} seed {seed} calls {calls} shards {cuts}: {'ok' if ok else 'MISMATCH'}{'' if shards_ok else ' (shards)'}", flush=True)
     bad += 0 if ok else 1
     g.close(); o.close()
 print("mismatches:", bad)
