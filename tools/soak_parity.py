@@ -18,7 +18,7 @@ bad = 0
 for k in range(n_cases):
     scene = ["s1", "sunlit", "dense", "s6"][int(rng.integers(0, 4))]
     W, H = int(rng.integers(40, 400)), int(rng.integers(24, 240))
-    depth, seed = int(rng.integers(1, 9)), int(rng.integers(0, 1 << 30))
+    depth, seed = int([1, 2, 3, 4, 5, 6, 8, 12, 15, 16, 20][int(rng.integers(0, 11))]), int(rng.integers(0, 1 << 30))  # > 15: the fused kernel
     calls = [int(rng.integers(1, 9)) for _ in range(int(rng.integers(1, 5)))]  # accumulate(n) calls: fused 4 + remainder, several launches
     mat, rgb, params = scenes.SCENES[scene](int(rng.integers(0, 5)))
     params = dict(params, use_physical_sky=0, use_clouds=0)

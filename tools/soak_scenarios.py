@@ -40,7 +40,7 @@ for k in range(n_cases):
         r = int(rng.integers(0, 10))
         if r < 4: script.append(("acc", int(rng.integers(1, 7))))
         elif r < 6:
-            jitter += 1; script.append(("still", jitter)); script.append(("acc", int(rng.integers(1, 6))))
+            jitter += 1; script.append(("still", jitter, [3.0, 8.0, 999999999.0][int(rng.integers(0, 3))])); script.append(("acc", int(rng.integers(1, 6))))
         elif r < 8:
             jitter += 1; script.append(("move", float(rng.uniform(0.3, 0.5)), jitter, [0.5, 0.5, 0.75, 1.0][int(rng.integers(0, 4))])); script.append(("acc", 1))
         elif r == 8: script.append(("reset",) if rng.integers(0, 2) else ("voxels", int(rng.integers(0, 6))))
@@ -64,7 +64,7 @@ for k in range(n_cases):
     for i, step in enumerate(script):
         for s in (o, e):
             if step[0] == "acc": s.accumulate(step[1])
-            elif step[0] == "still": s.end_frame(); s.set_camera(host.default_camera(W, H, jitter_index=step[1]))
+            elif step[0] == "still": s.end_frame(); s.set_camera(host.default_camera(W, H, jitter_index=step[1], max_accum_frames=float(step[2])))
             elif step[0] == "move":
                 pos = (step[1], 0.5, 2.0); view, proj = camera.default_matrices(W, H, pos=pos)
                 s.end_frame(); s.set_camera(host.make_camera(view, proj, pos, jitter_index=step[2], moving=True, render_scale=step[3], max_accum_frames=50.0))
