@@ -368,3 +368,22 @@ def test_overlapped_launches_match_oracle(monkeypatch):
     g2.accumulate(4)
     g2.accumulate(4)
     assert np.array_equal(g2.fetch_hdr().view(np.uint32), final.view(np.uint32))
+
+
+def test_full_frame_config2_matches_oracle(render_schedule):
+    """BASELINE config 2 at its real size -- 1920x1080, 8 bounces, one fused call of 4 samples -- against the oracle,
+    bit for bit (8.3 M path-samples: about 20 s of oracle time on 16 host threads; pooled schedule only)."""
+    if render_schedule != "pool":
+        pytest.skip("one schedule is enough at this size")
+    mat, rgb, params = scenes.scene_s1(0)
+    W, H = 1920, 1080
+    cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=8, seed=0)
+    g, o = gpu_session(cfg), orc.Oracle(cfg, threads=16)
+    for s in (g, o):
+        orc.setup(s, mat, rgb, params)
+        s.accumulate(4)
+    a, b = g.fetch_hdr(), o.fetch_hdr()
+    assert rel_l2(a, b) <= REL_L2_TOL
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a != b).sum()} values differ"
+    for which in (_abi.BUF_GBUF_DEPTH, _abi.BUF_GBUF_NORMAL, _abi.BUF_GBUF_MAT, _abi.BUF_HISTORY_DIFFUSE, _abi.BUF_HISTORY_SPECULAR):
+        assert np.array_equal(g.fetch_buffer(which).view(np.uint8), o.fetch_buffer(which).view(np.uint8)), which
