@@ -222,6 +222,21 @@ struct GrisBuffers {
     ReservoirRec* res_out;
 };
 
+// pathtracer.py:883-906: tap i of the golden-angle spiral around (u, v); false for the centre itself and for taps
+// outside the image (the reference reads out of bounds there)
+VRT_DEV bool gris_tap(const FrameParams& fp, int u, int v, int i, float angle_shift, float radius_shift, float max_radius,
+                      int max_taps, int& tx, int& ty) {
+    const float golden = 2.399963229728f;
+    float angle = ((float)i + angle_shift) * golden;
+    float rad = dm_sqrt(((float)i + radius_shift) / (float)max_taps) * max_radius;
+    float sa, ca;
+    dm_sincos(angle, &sa, &ca);
+    int ox = dm_f2i(ca * rad), oy = dm_f2i(sa * rad);
+    tx = u + ox; ty = v + oy;
+    if (ox == 0 && oy == 0) return false;
+    return !(tx < 0 || ty < 0 || tx >= fp.W || ty >= fp.H);
+}
+
 // pathtracer.py:815-989, called as spatial_GRIS(0, 24.0, 32, 1) (:1313)
 template <class PyrT>
 VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& P, const GrisBuffers& gb, int u, int v,
@@ -269,26 +284,29 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     // The reference's tap loop does two independent things per accepted tap: (1) shift the CENTRE sample into the
     // neighbour's domain to grow the canonical MIS weight (:917-931), (2) shift the NEIGHBOUR's sample into the centre's
     // domain and stream it through the output reservoir (:922-956).  (1) only sums into canonical_mis, (2) only draws
-    // from the random stream; run as two loops over the same taps, in tap order, every sum and draw keeps its place
+    // from the random stream; run as separate loops over the same taps, in tap order, every sum and draw keeps its place
     // while each loop carries one shift's worth of live state instead of two (k_gris is register bound).
+    // A first cheap loop only decides which taps pass the geometric test (:883-912); the two expensive loops then walk
+    // each pixel's OWN accepted taps (ascending, so the order of sums and draws is the reference's): a wave runs as many
+    // trips as its busiest pixel accepted taps instead of all 32 with the rejected pixels' lanes idle.
     unsigned accepted = 0u;  // max_taps <= 32
     for (int i = 0; i < max_taps; i++) {
-        const float golden = 2.399963229728f;
-        float angle = ((float)i + angle_shift) * golden;
-        float rad = dm_sqrt(((float)i + radius_shift) / (float)max_taps) * max_radius;
-        float sa, ca;
-        dm_sincos(angle, &sa, &ca);
-        int ox = dm_f2i(ca * rad), oy = dm_f2i(sa * rad);
-        if (ox == 0 && oy == 0) continue;
-        int tx = u + ox, ty = v + oy;
-        if (tx < 0 || ty < 0 || tx >= fp.W || ty >= fp.H) continue;
+        int tx, ty;
+        if (!gris_tap(fp, u, v, i, angle_shift, radius_shift, max_radius, max_taps, tx, ty)) continue;
         const int t = (ty - fp.row0) * fp.W + tx;
-        const f2 ttc = pixel_texcoord(fp, (float)tx, (float)ty);
         const f3 nn1 = oct_decode(gb.gb_normal[t]);
-        const f3 nx1 = xform(fp.view_inv, screen_to_view(ttc, gb.gb_depth[t], fp.proj_inv), 1.0f);
+        const f3 nx1 = xform(fp.view_inv, screen_to_view(pixel_texcoord(fp, (float)tx, (float)ty), gb.gb_depth[t], fp.proj_inv), 1.0f);
         const float ndist = len3(nx1 - fp.camera_pos);
         if (dm_abs(ndist - cdist) > 0.1f * cdist || dot3(cn1, nn1) < 0.5f) continue;  // :912
         accepted |= 1u << i;
+    }
+    for (unsigned m = accepted; m != 0u; m &= m - 1u) {
+        const int i = __builtin_ctz(m);
+        int tx, ty;
+        (void)gris_tap(fp, u, v, i, angle_shift, radius_shift, max_radius, max_taps, tx, ty);
+        const int t = (ty - fp.row0) * fp.W + tx;
+        const f3 nn1 = oct_decode(gb.gb_normal[t]);
+        const f3 nx1 = xform(fp.view_inv, screen_to_view(pixel_texcoord(fp, (float)tx, (float)ty), gb.gb_depth[t], fp.proj_inv), 1.0f);
         const float nb_M = dm_f16_to_f32((uint16_t)(gb.res_in[t].M_W & 0xffffu));
         int nmat_id;
         const Material nmat = material_from_bits(sc.mats, gb.gb_mat[t], nmat_id);
@@ -302,14 +320,11 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         cw /= c_p_hat * nb_M + lum(center.z.F) * center.M / (float)max_taps;
         canonical_mis += 1.0f - cw;
     }
-    for (int i = 0; i < max_taps; i++) {
-        if (((accepted >> i) & 1u) == 0u) continue;
-        const float golden = 2.399963229728f;
-        float angle = ((float)i + angle_shift) * golden;
-        float rad = dm_sqrt(((float)i + radius_shift) / (float)max_taps) * max_radius;
-        float sa, ca;
-        dm_sincos(angle, &sa, &ca);
-        const int t = (v + dm_f2i(sa * rad) - fp.row0) * fp.W + u + dm_f2i(ca * rad);
+    for (unsigned m = accepted; m != 0u; m &= m - 1u) {
+        const int i = __builtin_ctz(m);
+        int tx, ty;
+        (void)gris_tap(fp, u, v, i, angle_shift, radius_shift, max_radius, max_taps, tx, ty);
+        const int t = (ty - fp.row0) * fp.W + tx;
         Reservoir nb;
         reservoir_init(nb);
         reservoir_decode(nb, gb.res_in[t]);
