@@ -25,7 +25,9 @@ struct Emu {
     std::vector<uint32_t> grid;
     std::vector<unsigned long long> l0, l1, l2, l0c;
     std::vector<uint32_t> l0c_base;  // [512] + count
-    std::vector<float> mats, sky_scat, sky_trans;
+    std::vector<float> mats, mats_x, sky_scat, sky_trans;
+    std::vector<GrisGeo> gris_geo;
+    std::vector<GrisSrc> gris_src;
     int buf0, buf1, own0, own1;
     size_t n;
     std::vector<f3> cbuf[2], color_s, color_d2, color_s2, gb_pos;
@@ -136,7 +138,11 @@ int emu_upload_voxels(Emu* c, const int8_t* mat, const uint8_t* rgb) {
     c->l0c_base[512] = k;
     return 0;
 }
-int emu_upload_materials(Emu* c, const float* t) { memcpy(c->mats.data(), t, 128 * 14 * 4); return 0; }
+static void derive_materials(Emu* c) {
+    c->mats_x.assign(128 * 8, 0.0f);
+    for (int id = 0; id < 128; id++) store_mat_derived(c->mats_x.data(), id, mat_derive(load_material(c->mats.data(), id)));
+}
+int emu_upload_materials(Emu* c, const float* t) { memcpy(c->mats.data(), t, 128 * 14 * 4); derive_materials(c); return 0; }
 int emu_upload_cloud_texture(Emu*, const uint8_t*) { return 0; }
 int emu_set_scene(Emu* c, const vrt_scene_params* s) { c->scene = *s; return 0; }
 int emu_set_camera(Emu* c, const vrt_camera* cam) { c->cam = *cam; return 0; }
@@ -239,6 +245,11 @@ int emu_accumulate(Emu* c, int n_samples) {
             gb.color_d_out = c->color_d2.data(); gb.color_s_out = c->color_s2.data();
             gb.gb_normal = out.gb_normal; gb.gb_depth = out.gb_depth; gb.gb_mat = out.gb_mat;
             gb.res_in = c->res[0].data(); gb.res_out = c->res[1].data();
+            c->gris_geo.resize((size_t)(fp.row1 - fp.row0) * fp.W); c->gris_src.resize(c->gris_geo.size());
+            if (c->mats_x.empty()) derive_materials(c);
+            gb.geo = c->gris_geo.data(); gb.src = c->gris_src.data(); gb.mats_x = c->mats_x.data();
+            for (int v = fp.row0; v < fp.row1; v++)
+                for (int u = 0; u < fp.W; u++) gris_prepare_pixel(fp, gb, u, v);
             GlobalPyramid P;
             P.p = sc.pyr;
             int g0 = c->own0 - 2 < c->buf0 ? c->buf0 : c->own0 - 2, g1 = c->own1 + 2 > c->buf1 ? c->buf1 : c->own1 + 2;

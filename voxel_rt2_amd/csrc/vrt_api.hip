@@ -73,6 +73,9 @@ struct vrt_ctx {
     f4 *d_hist_d[2] = {nullptr, nullptr}, *d_hist_s[2] = {nullptr, nullptr};
     f4* d_ldr = nullptr;
     ReservoirRec* d_res[2] = {nullptr, nullptr};
+    GrisGeo* d_gris_geo = nullptr;   // per-pixel records of k_gris's prepare pass (vrt_restir.h)
+    GrisSrc* d_gris_src = nullptr;
+    float* d_mats_x = nullptr;       // [128][8] mat_derive() of every material row
     int cur = 0;      // g-buffer rotation: render writes [cur], temporal reads [prev_gb] as "prev"
     int prev_gb = 3;  // the copy the most recent launch wrote
     // Overlapped launches (vrt_accumulate): VRT_SETS copies (set 0 = the canonical buffers, alt_*[s - 1] the others) of
@@ -240,7 +243,9 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
         ok = ok && dalloc(&c->d_hist_d[s], n) == hipSuccess && dalloc(&c->d_hist_s[s], n) == hipSuccess;
         if (cfg->use_restir) ok = ok && dalloc(&c->d_res[s], n) == hipSuccess;
     }
-    if (cfg->use_restir) ok = ok && dalloc(&c->d_color_d2, n) == hipSuccess && dalloc(&c->d_color_s2, n) == hipSuccess;
+    if (cfg->use_restir) ok = ok && dalloc(&c->d_color_d2, n) == hipSuccess && dalloc(&c->d_color_s2, n) == hipSuccess &&
+                              dalloc(&c->d_gris_geo, n) == hipSuccess && dalloc(&c->d_gris_src, n) == hipSuccess;
+    ok = ok && dalloc(&c->d_mats_x, 128 * 8) == hipSuccess;
     if (cfg->sky_res > 0) {
         size_t ns = (size_t)cfg->sky_res * cfg->sky_res * 3;
         ok = ok && dalloc(&c->d_sky_scat, ns) == hipSuccess && dalloc(&c->d_sky_trans, ns) == hipSuccess;
@@ -258,6 +263,7 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
         const float row[14] = {1, 1, 1, 0, 0, 0.04f, 0, 0.9f, 0, 0, 0, 0, 0, 0};
         for (int i = 0; i < 128; i++) memcpy(&t[14 * i], row, sizeof(row));
         hipMemcpy(c->d_mats, t.data(), t.size() * 4, hipMemcpyHostToDevice);
+        launch_mat_derived(c->stream, c->d_mats, c->d_mats_x);
     }
     memset(&c->scene, 0, sizeof(c->scene));
     c->scene.floor_color[0] = c->scene.floor_color[1] = c->scene.floor_color[2] = 1.0f;  // pathtracer.py:91-93
@@ -286,7 +292,7 @@ void vrt_destroy(vrt_ctx* c) {
                     c->d_sky_trans, c->d_cloud_ambient, c->d_trans_lut, c->d_cloud_tex, c->d_cbuf[0], c->d_cbuf[1], c->d_spec_planes, c->d_color_d2,
                     c->d_color_s2, c->d_gb_pos, c->d_gb_normal[0], c->d_gb_normal[1], c->d_gb_depth[0], c->d_gb_depth[1],
                     c->d_gb_mat, c->d_refl_planes, c->d_gb_refl_f, c->d_hist_d[0], c->d_hist_d[1], c->d_hist_s[0], c->d_hist_s[1],
-                    c->d_ldr, c->d_res[0], c->d_res[1], c->d_multi_d, c->d_pool_scratch};
+                    c->d_ldr, c->d_res[0], c->d_res[1], c->d_multi_d, c->d_pool_scratch, c->d_gris_geo, c->d_gris_src, c->d_mats_x};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (c->stream && c->owns_stream) hipStreamDestroy(c->stream);
@@ -307,6 +313,7 @@ int vrt_upload_materials(vrt_ctx* c, const float* table) {
     if (!c || !table) return fail(VRT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->d_mats, table, 128 * 14 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_mat_derived(c->stream, c->d_mats, c->d_mats_x));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return VRT_OK;
 }
@@ -550,6 +557,7 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
             gb.color_d_in = rt; gb.color_s_in = c->d_color_s; gb.color_d_out = c->d_color_d2; gb.color_s_out = c->d_color_s2;
             gb.gb_normal = out.gb_normal; gb.gb_depth = out.gb_depth; gb.gb_mat = out.gb_mat;
             gb.res_in = c->d_res[0]; gb.res_out = c->d_res[1];
+            gb.geo = c->d_gris_geo; gb.src = c->d_gris_src; gb.mats_x = c->d_mats_x;
             int g0 = c->own0 - 2 < c->buf0 ? c->buf0 : c->own0 - 2, g1 = c->own1 + 2 > c->buf1 ? c->buf1 : c->own1 + 2;
             if (record(c, 2, &a, &b) != VRT_OK) return VRT_E_DEVICE;
             HIP_TRY(hipEventRecord(a, c->stream));

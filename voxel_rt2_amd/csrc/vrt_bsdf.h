@@ -59,19 +59,31 @@ struct Surf {
     float n_v, v_x, v_y;   // view projections
 };
 
-VRT_DEV void surf_init(Surf& s, const Material& m, f3 n, f3 v) {
-    s.m = m; s.n = n; s.v = v;
-    ortho_basis(n, s.tx, s.ty);
+// The part of a shading point that depends on the material row alone (not on its base colour): one table entry per
+// material id for callers that set up many surfaces (spatial reuse), computed by the same expressions.
+struct MatDerived { float ax, ay, cc_alpha, w_d, w_s, w_c; };
+VRT_DEV MatDerived mat_derive(const Material& m) {
+    MatDerived x;
     float aspect = dm_sqrt(1.0f - 0.9f * m.anisotropic);
-    s.ax = dm_max(sq(m.roughness) / aspect, 1e-3f);
-    s.ay = dm_max(sq(m.roughness) * aspect, 1e-3f);
-    s.cc_alpha = lerp1(0.1f, 0.001f, m.clearcoat_gloss);
+    x.ax = dm_max(sq(m.roughness) / aspect, 1e-3f);
+    x.ay = dm_max(sq(m.roughness) * aspect, 1e-3f);
+    x.cc_alpha = lerp1(0.1f, 0.001f, m.clearcoat_gloss);
     float dw = (1.0f - m.metallic) * dm_clamp(1.0f - m.specular, 0.4f, 0.9f);
     float sw = 1.0f - dw;
     float cw = m.clearcoat * 0.7f;
     float sum = dw + sw + cw;
-    s.w_d = dw / sum; s.w_s = sw / sum; s.w_c = cw / sum;
+    x.w_d = dw / sum; x.w_s = sw / sum; x.w_c = cw / sum;
+    return x;
+}
+VRT_DEV void surf_set(Surf& s, const Material& m, const MatDerived& x, f3 n, f3 v, f3 tx, f3 ty) {
+    s.m = m; s.n = n; s.v = v; s.tx = tx; s.ty = ty;
+    s.ax = x.ax; s.ay = x.ay; s.cc_alpha = x.cc_alpha; s.w_d = x.w_d; s.w_s = x.w_s; s.w_c = x.w_c;
     s.n_v = dot3(n, v); s.v_x = dot3(v, s.tx); s.v_y = dot3(v, s.ty);
+}
+VRT_DEV void surf_init(Surf& s, const Material& m, f3 n, f3 v) {
+    f3 tx, ty;
+    ortho_basis(n, tx, ty);
+    surf_set(s, m, mat_derive(m), n, v, tx, ty);
 }
 
 VRT_DEV float gtr2_aniso(float nh, float hx, float hy, float ax, float ay) {  // :69-71

@@ -509,6 +509,17 @@ __global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES) void k_gris(FrameParams fp
     if (INSTR) flush_stats(ts, sc.counters);
 }
 
+// once per pixel of every row the launch holds: the records k_gris reads ~32 times per pixel (vrt_restir.h)
+__global__ __launch_bounds__(256) void k_gris_prepare(FrameParams fp, GrisBuffers gb) {
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int v = fp.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u < fp.W && v < fp.row1) gris_prepare_pixel(fp, gb, u, v);
+}
+__global__ void k_mat_derived(const float* mats, float* mats_x) {
+    const int id = threadIdx.x;
+    if (id < 128) store_mat_derived(mats_x, id, mat_derive(load_material(mats, id)));
+}
+
 // ---- temporal accumulation + presentation ------------------------------------------------------
 // Register budgets chosen together (overlapped launches, vrt_api.hip): two pooled render waves at 208 registers leave
 // 96 of a SIMD's 512, which is what this kernel is held to, so that a temporal pass runs on the same CUs BESIDE the next
@@ -637,7 +648,13 @@ hipError_t launch_render_pool(hipStream_t st, bool instr, int n_blocks, const Fr
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
+hipError_t launch_mat_derived(hipStream_t st, const float* mats, float* mats_x) {
+    hipLaunchKernelGGL(k_mat_derived, dim3(1), dim3(128), 0, st, mats, mats_x);
+    VRT_LAUNCH_CHECK();
+    return hipSuccess;
+}
 hipError_t launch_gris(hipStream_t st, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1) {
+    hipLaunchKernelGGL(k_gris_prepare, dim3((fp.W + 63) / 64, (fp.row1 - fp.row0 + 3) / 4), dim3(256), 0, st, fp, gb);
     dim3 g((fp.W + 15) / 16, (r1 - r0 + 15) / 16), b(256);
     if (instr) hipLaunchKernelGGL((k_gris<true>), g, b, 0, st, fp, sc, gb, r0, r1);
     else hipLaunchKernelGGL((k_gris<false>), g, b, 0, st, fp, sc, gb, r0, r1);

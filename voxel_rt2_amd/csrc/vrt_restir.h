@@ -141,11 +141,24 @@ VRT_DEV Material material_from_bits(const float* mats, uint32_t enc, int& id) { 
     return m;
 }
 
+VRT_DEV MatDerived load_mat_derived(const float* mats_x, int id) {
+    const float* p = mats_x + 8 * (id & 127);
+    MatDerived x;
+    x.ax = p[0]; x.ay = p[1]; x.cc_alpha = p[2]; x.w_d = p[3]; x.w_s = p[4]; x.w_c = p[5];
+    return x;
+}
+VRT_DEV void store_mat_derived(float* mats_x, int id, const MatDerived& x) {
+    float* p = mats_x + 8 * id;
+    p[0] = x.ax; p[1] = x.ay; p[2] = x.cc_alpha; p[3] = x.w_d; p[4] = x.w_s; p[5] = x.w_c; p[6] = 0.0f; p[7] = 0.0f;
+}
+
 // pathtracer.py:672-812: shift `src`'s sample to the primary vertex at dst_pos whose shading frame is `ds`
 // (normal, material, view direction toward the camera -- built by the caller so the centre pixel's frame, which is
 // the destination of every neighbour's shift, is set up once per pixel instead of once per tap)
-VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, f3 dst_pos, const Surf& ds,
-                          const Reservoir& src, f3& out_d, f3& out_s, float& out_jac, TraceStats& ts) {
+// `rc_ty` is the bitangent of the sample's reconnection vertex (ortho_basis of rc_normal, which does not depend on the
+// destination), `mats_x` the per-material-id table of mat_derive().
+VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const float* mats_x, f3 dst_pos, const Surf& ds,
+                          const Reservoir& src, f3 rc_ty, f3& out_d, f3& out_s, float& out_jac, TraceStats& ts) {
     const bool escape = near_zero3(src.z.rc_normal);
     const bool last = near_zero3(src.z.rc_incident_dir);
     const bool nee_vis = !near_zero3(src.z.rc_nee_dir);
@@ -159,7 +172,7 @@ VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, f3 dst_pos
     f3 contrib = mk3(0.0f);
     if (!escape) {
         Surf rc;
-        surf_init(rc, rc_mat, src.z.rc_normal, -to_rc);
+        surf_set(rc, rc_mat, load_mat_derived(mats_x, rc_id), src.z.rc_normal, -to_rc, cross3(src.z.rc_normal, rc_ty), rc_ty);
         if (!last) {
             f3 bd, bs;
             eval_lobes(rc, src.z.rc_incident_dir, src.z.lobes / 10, bd, bs);
@@ -210,7 +223,30 @@ VRT_DEV uint32_t hash3(uint32_t x, uint32_t y, uint32_t z) {  // math_utils.py:2
     return x;
 }
 
+// What the spatial-reuse kernel needs of a pixel each of the ~32 times it is somebody's neighbour, worked out once per
+// pixel by gris_prepare_pixel() instead (same expressions, so the same bits): the primary vertex as the destination of a
+// shift (GrisGeo, pathtracer.py:896-912 + 731-732) and the decoded reservoir as the source of one (GrisSrc,
+// reservoir.py:126-141).  16-byte aligned so that a tap is four / seven 128-bit loads.
+struct alignas(16) GrisGeo {
+    f3 n; float dist;        // g-buffer normal; distance of x1 from the camera  (the two the acceptance test reads)
+    f3 x1; uint32_t mat;     // primary vertex from the g-buffer depth; packed material
+    f3 v; float M;           // unit vector toward the camera; the pixel's reservoir M
+    f3 ty; uint32_t pad;     // bitangent of ortho_basis(n); the tangent is cross(n, ty)
+};
+struct alignas(16) GrisSrc {
+    f3 F; float M;
+    f3 rc_pos; float weight;
+    f3 rc_normal; float jac;
+    f3 rc_incident_dir; int lobes;
+    f3 rc_incident_L; uint32_t rc_mat_info;
+    f3 rc_nee_dir; uint32_t pad0;
+    f3 rc_ty; uint32_t pad1;  // bitangent of ortho_basis(rc_normal)
+};
+
 struct GrisBuffers {
+    GrisGeo* geo;            // [rows of the launch][W], written by the prepare pass
+    GrisSrc* src;
+    const float* mats_x;     // [128][8]: mat_derive() of every material id
     const f3* color_d_in;
     const f3* color_s_in;
     f3* color_d_out;
@@ -221,6 +257,37 @@ struct GrisBuffers {
     const ReservoirRec* res_in;
     ReservoirRec* res_out;
 };
+
+// once per pixel of every row the launch holds (the rows it renders and their halo)
+VRT_DEV void gris_prepare_pixel(const FrameParams& fp, const GrisBuffers& gb, int u, int v) {
+    const int idx = (v - fp.row0) * fp.W + u;
+    GrisGeo g;
+    g.n = oct_decode(gb.gb_normal[idx]);
+    g.x1 = xform(fp.view_inv, screen_to_view(pixel_texcoord(fp, (float)u, (float)v), gb.gb_depth[idx], fp.proj_inv), 1.0f);
+    g.dist = len3(g.x1 - fp.camera_pos);
+    g.mat = gb.gb_mat[idx];
+    g.v = norm3(fp.camera_pos - g.x1);
+    Reservoir r;
+    reservoir_init(r);
+    reservoir_decode(r, gb.res_in[idx]);
+    g.M = r.M;
+    f3 tx;
+    ortho_basis(g.n, tx, g.ty);
+    g.pad = 0u;
+    gb.geo[idx] = g;
+    GrisSrc s;
+    s.F = r.z.F; s.M = r.M; s.rc_pos = r.z.rc_pos; s.weight = r.weight; s.rc_normal = r.z.rc_normal; s.jac = r.z.jac;
+    s.rc_incident_dir = r.z.rc_incident_dir; s.lobes = r.z.lobes; s.rc_incident_L = r.z.rc_incident_L;
+    s.rc_mat_info = r.z.rc_mat_info; s.rc_nee_dir = r.z.rc_nee_dir; s.pad0 = 0u; s.pad1 = 0u;
+    ortho_basis(r.z.rc_normal, tx, s.rc_ty);
+    gb.src[idx] = s;
+}
+VRT_DEV void gris_load_src(Reservoir& r, f3& rc_ty, const GrisSrc& s) {
+    r.z.F = s.F; r.M = s.M; r.z.rc_pos = s.rc_pos; r.weight = s.weight; r.z.rc_normal = s.rc_normal; r.z.jac = s.jac;
+    r.z.rc_incident_dir = s.rc_incident_dir; r.z.lobes = s.lobes; r.z.rc_incident_L = s.rc_incident_L;
+    r.z.rc_mat_info = s.rc_mat_info; r.z.rc_nee_dir = s.rc_nee_dir;
+    rc_ty = s.rc_ty;
+}
 
 // pathtracer.py:883-906: tap i of the golden-angle spiral around (u, v); false for the centre itself and for taps
 // outside the image (the reference reads out of bounds there)
@@ -251,7 +318,6 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         return;
     }
     dm_rng rng = dm_rng_init(fp.seed, fp.frame, (uint32_t)(v * fp.W + u), 1u);
-    const f2 tc = pixel_texcoord(fp, (float)u, (float)v);
     (void)dm_rng_f32(&rng);  // start_index draw (:827), value unused
     const uint32_t sx = (pass_id == 0) ? ((uint32_t)u >> 3) : 2u, sy = (pass_id == 0) ? ((uint32_t)v >> 3) : 2u;
     const uint32_t hs = hash3(sx, sy, 0u + (uint32_t)pass_id);
@@ -259,14 +325,14 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     const float radius_shift = dm_rng_f32(&rng);
 
     Reservoir center, outr;
-    reservoir_init(center);
-    reservoir_decode(center, gb.res_in[idx]);
+    f3 center_rc_ty;
+    gris_load_src(center, center_rc_ty, gb.src[idx]);
     reservoir_init(outr);
 
-    const float cdepth = gb.gb_depth[idx];
-    const f3 cx1 = xform(fp.view_inv, screen_to_view(tc, cdepth, fp.proj_inv), 1.0f);
-    const float cdist = len3(cx1 - fp.camera_pos);
-    const f3 cn1 = oct_decode(gb.gb_normal[idx]);
+    const GrisGeo cg = gb.geo[idx];
+    const f3 cx1 = cg.x1;
+    const float cdist = cg.dist;
+    const f3 cn1 = cg.n;
     if (near_zero3(cx1)) {
         gb.color_d_out[idx] = center.z.F;
         gb.color_s_out[idx] = gb.color_s_in[idx];
@@ -274,9 +340,9 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         return;
     }
     int cmat_id;
-    const Material cmat = material_from_bits(sc.mats, gb.gb_mat[idx], cmat_id);
+    const Material cmat = material_from_bits(sc.mats, cg.mat, cmat_id);
     Surf cds;  // the centre pixel's shading frame (pathtracer.py:731-732 with dst = centre)
-    surf_init(cds, cmat, cn1, norm3(fp.camera_pos - cx1));
+    surf_set(cds, cmat, load_mat_derived(gb.mats_x, cmat_id), cn1, cg.v, cross3(cn1, cg.ty), cg.ty);
     int valid = 0;
     float canonical_mis = 1.0f;
     f3 chosen_d = mk3(0.0f), chosen_s = mk3(0.0f);
@@ -293,10 +359,9 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     for (int i = 0; i < max_taps; i++) {
         int tx, ty;
         if (!gris_tap(fp, u, v, i, angle_shift, radius_shift, max_radius, max_taps, tx, ty)) continue;
-        const int t = (ty - fp.row0) * fp.W + tx;
-        const f3 nn1 = oct_decode(gb.gb_normal[t]);
-        const f3 nx1 = xform(fp.view_inv, screen_to_view(pixel_texcoord(fp, (float)tx, (float)ty), gb.gb_depth[t], fp.proj_inv), 1.0f);
-        const float ndist = len3(nx1 - fp.camera_pos);
+        const GrisGeo* ng = &gb.geo[(ty - fp.row0) * fp.W + tx];
+        const f3 nn1 = ng->n;
+        const float ndist = ng->dist;
         if (dm_abs(ndist - cdist) > 0.1f * cdist || dot3(cn1, nn1) < 0.5f) continue;  // :912
         accepted |= 1u << i;
     }
@@ -304,17 +369,15 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         const int i = __builtin_ctz(m);
         int tx, ty;
         (void)gris_tap(fp, u, v, i, angle_shift, radius_shift, max_radius, max_taps, tx, ty);
-        const int t = (ty - fp.row0) * fp.W + tx;
-        const f3 nn1 = oct_decode(gb.gb_normal[t]);
-        const f3 nx1 = xform(fp.view_inv, screen_to_view(pixel_texcoord(fp, (float)tx, (float)ty), gb.gb_depth[t], fp.proj_inv), 1.0f);
-        const float nb_M = dm_f16_to_f32((uint16_t)(gb.res_in[t].M_W & 0xffffu));
+        const GrisGeo ng = gb.geo[(ty - fp.row0) * fp.W + tx];
+        const float nb_M = ng.M;
         int nmat_id;
-        const Material nmat = material_from_bits(sc.mats, gb.gb_mat[t], nmat_id);
+        const Material nmat = material_from_bits(sc.mats, ng.mat, nmat_id);
         f3 cd, cs;
         float cjac;
         Surf nds;
-        surf_init(nds, nmat, nn1, norm3(fp.camera_pos - nx1));
-        shift_sample(fp, sc, nx1, nds, center, cd, cs, cjac, ts);
+        surf_set(nds, nmat, load_mat_derived(gb.mats_x, nmat_id), ng.n, ng.v, cross3(ng.n, ng.ty), ng.ty);
+        shift_sample(fp, sc, gb.mats_x, ng.x1, nds, center, center_rc_ty, cd, cs, cjac, ts);
         float c_p_hat = lum(cd + cs) * cjac;
         float cw = c_p_hat * nb_M;
         cw /= c_p_hat * nb_M + lum(center.z.F) * center.M / (float)max_taps;
@@ -324,13 +387,12 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         const int i = __builtin_ctz(m);
         int tx, ty;
         (void)gris_tap(fp, u, v, i, angle_shift, radius_shift, max_radius, max_taps, tx, ty);
-        const int t = (ty - fp.row0) * fp.W + tx;
         Reservoir nb;
-        reservoir_init(nb);
-        reservoir_decode(nb, gb.res_in[t]);
+        f3 nb_rc_ty;
+        gris_load_src(nb, nb_rc_ty, gb.src[(ty - fp.row0) * fp.W + tx]);
         f3 sd, ss;
         float jac;
-        shift_sample(fp, sc, cx1, cds, nb, sd, ss, jac, ts);
+        shift_sample(fp, sc, gb.mats_x, cx1, cds, nb, nb_rc_ty, sd, ss, jac, ts);
 
         float p_hat = lum(sd + ss);
         float p_hat_n = p_hat / jac;
