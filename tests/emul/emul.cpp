@@ -254,7 +254,14 @@ int emu_accumulate(Emu* c, int n_samples) {
             P.p = sc.pyr;
             int g0 = c->own0 - 2 < c->buf0 ? c->buf0 : c->own0 - 2, g1 = c->own1 + 2 > c->buf1 ? c->buf1 : c->own1 + 2;
             for (int v = g0; v < g1; v++)
-                for (int u = 0; u < fp.W; u++) gris_pixel(fp, sc, P, gb, u, v, 0, 24.0f, 32, 1, c->ts);
+                for (int u = 0; u < fp.W; u++) {
+                    float cs[64];
+                    uint16_t off[32];
+                    for (int i = 0; i < 32; i++) gris_tap_cs(u, v, 0, i, cs);
+                    GrisTaps taps;
+                    taps.cs = cs; taps.off = off; taps.off_stride = 1;
+                    gris_pixel(fp, sc, P, gb, taps, u, v, 0, 24.0f, 32, 1, c->ts);
+                }
             cd = c->color_d2.data();
             cs = c->color_s2.data();
         } else if (getenv("VRT_EMU_POOL")) {

@@ -188,6 +188,94 @@ VRT_DEV float pdf_lobe(const Surf& s, f3 l, int lobe) {
     return pdf;
 }
 
+// ---- several directions at one shading point (spatial reuse) ---------------------------------------------------
+// eval_lobes() and the pdfs above re-derive, per call, terms that depend on the material and the view vector only, and
+// an eval + pdf pair for the same direction derives the half vector and the two distributions twice.  The reconnection
+// shift (vrt_restir.h) evaluates two directions with their pdfs at one vertex ~64 times per pixel: SurfShared holds the
+// per-vertex terms, bsdf_eval_pdf() is eval_lobes() + pdf_lobe() / pdf_all() for one direction with the shared terms
+// worked out once.  Every expression is the one above (same operands, same order), so the values are the same bits.
+struct SurfShared {
+    f3 lambert, sheen_col, spec_col;   // eval_diffuse's base / pi and sheen * mix(1, tint, sheen_tint); eval_specular's spec_col
+    float fv, g_v, gc_v;               // pow5(1 - n.v); smith_aniso and smith_iso(0.25) of the view vector
+};
+// groups: d = what the diffuse lobe reads, sp = the specular lobe's, cc = the clearcoat lobe's (unrequested fields stay 0)
+VRT_DEV SurfShared surf_shared(const Surf& s, bool d, bool sp, bool cc) {
+    SurfShared c;
+    c.lambert = mk3(0.0f); c.sheen_col = mk3(0.0f); c.spec_col = mk3(0.0f); c.fv = 0.0f; c.g_v = 0.0f; c.gc_v = 0.0f;
+    const Material& m = s.m;
+    if (d || sp) {
+        const f3 tint = tint_of(m.base);
+        if (d) {
+            c.lambert = m.base / DM_PI;
+            c.sheen_col = m.sheen * lerp3(mk3(1.0f), tint, m.sheen_tint);
+            c.fv = dm_pow5(1.0f - s.n_v);
+        }
+        if (sp) {
+            c.spec_col = lerp3(m.specular * 0.08f * lerp3(mk3(1.0f), tint, m.specular_tint), m.base, m.metallic);
+            c.g_v = smith_aniso(s.n_v, s.v_x, s.v_y, s.ax, s.ay);
+        }
+    }
+    if (cc) c.gc_v = smith_iso(s.n_v, 0.25f);
+    return c;
+}
+VRT_DEV bool lobe_has(int lobe, int which) { return lobe == which || lobe == LOBE_ALL; }
+enum { PDF_NONE = 0, PDF_LOBE = 1, PDF_ALL = 2 };
+// out_d / out_s = eval_lobes(s, l, lobe);  pdf = pdf_lobe(s, l, lobe) (PDF_LOBE) or pdf_all(s, l) (PDF_ALL).
+// `c` must hold the groups of every lobe that is evaluated or whose pdf is taken.
+VRT_DEV void bsdf_eval_pdf(const Surf& s, const SurfShared& c, f3 l, int lobe, int pdf_mode, f3& out_d, f3& out_s, float& pdf) {
+    const Material& m = s.m;
+    out_d = mk3(0.0f);
+    out_s = mk3(0.0f);
+    const float nl = dot3(s.n, l);
+    const bool front = nl > 0.0f && s.n_v > 0.0f;
+    const bool e_d = front && lobe_has(lobe, LOBE_DIFFUSE), e_s = front && lobe_has(lobe, LOBE_SPEC), e_c = front && lobe_has(lobe, LOBE_CLEARCOAT);
+    const bool p_d = pdf_mode == PDF_ALL || (pdf_mode == PDF_LOBE && lobe == LOBE_DIFFUSE);
+    const bool p_s = pdf_mode == PDF_ALL || (pdf_mode == PDF_LOBE && lobe == LOBE_SPEC);
+    const bool p_c = pdf_mode == PDF_ALL || (pdf_mode == PDF_LOBE && lobe != LOBE_DIFFUSE && lobe != LOBE_SPEC);
+    const f3 h = norm3(l + s.v);
+    const float lh = dot3(l, h), nh = dot3(s.n, h);
+    float D = 0.0f, Dc = 0.0f;
+    if (e_s || p_s) D = gtr2_aniso(nh, dot3(h, s.tx), dot3(h, s.ty), s.ax, s.ay);
+    if (e_c || p_c) Dc = gtr1(dm_abs(nh), s.cc_alpha);
+    if (e_d) {  // eval_diffuse
+        float rr = 2.0f * m.roughness * sq(lh);
+        float fl = dm_pow5(1.0f - nl), fv = c.fv;
+        f3 retro = c.lambert * rr * (fl + fv + fl * fv * (rr - 1.0f));
+        f3 fd = c.lambert * (1.0f - 0.5f * fl) * (1.0f - 0.5f * fv) + retro;
+        f3 sheen = c.sheen_col * dm_pow5(1.0f - lh);
+        float fss90 = lh * lh * m.roughness;
+        float fss = lerp1(1.0f, fss90, fl) * lerp1(1.0f, fss90, fv);
+        float ss = 1.25f * (fss * (1.0f / (nl + s.n_v) - 0.5f) + 0.5f);
+        f3 sub = VRT_INV_PI * ss * m.base;
+        out_d = out_d + (lerp3(fd, sub, m.subsurface) + sheen) * (1.0f - m.metallic);
+    }
+    if (e_s) {  // eval_specular
+        float G = smith_aniso(nl, dot3(l, s.tx), dot3(l, s.ty), s.ax, s.ay) * c.g_v;
+        f3 F = lerp3(c.spec_col, mk3(1.0f), dm_pow5(1.0f - lh));
+        out_s = out_s + D * G * F;
+    }
+    if (e_c) {  // eval_clearcoat
+        float F = lerp1(0.04f, 1.0f, dm_pow5(1.0f - lh));
+        float G = smith_iso(nl, 0.25f) * c.gc_v;
+        out_s = out_s + mk3(m.clearcoat * Dc * F * G);
+    }
+    float pd = 0.0f, ps = 0.0f, pc = 0.0f;
+    if (p_d) pd = dm_saturate(nl) / DM_PI;
+    if (p_s) ps = c.g_v * dm_abs(lh) * D / dm_abs(nl);
+    if (p_c) { float anh = dm_abs(nh); pc = Dc * anh / (4.0f * dot3(s.v, h)); }
+    if (pdf_mode == PDF_ALL) {
+        pdf = 0.0f;
+        pdf += pd * s.w_d;
+        pdf += ps * s.w_s;
+        pdf += pc * s.w_c;
+    } else if (pdf_mode == PDF_LOBE) {
+        pdf = p_d ? pd * s.w_d : (p_s ? ps * s.w_s : pc * s.w_c);
+        if (dm_isinf(pdf) || dm_isnan(pdf)) pdf = 1.0f;
+    } else {
+        pdf = 0.0f;
+    }
+}
+
 VRT_DEV f3 reflect3(f3 i, f3 n) { return i - 2.0f * dot3(n, i) * n; }
 VRT_DEV f3 to_world(const Surf& s, f3 m) { return m.x * s.tx + m.z * s.ty + m.y * s.n; }  // (tangent, normal, bitangent) frame
 

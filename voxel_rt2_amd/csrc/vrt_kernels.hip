@@ -491,21 +491,38 @@ template <bool INSTR>
 #ifndef VRT_GRIS_MIN_WAVES
 #define VRT_GRIS_MIN_WAVES 2   // 256 registers, no spills; one wave per SIMD left the VALU idle a third of the time (6.6 vs 10.2 ms)
 #endif
-__global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES) void k_gris(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r1) {
+__global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES) void k_gris(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r1, int tiles_x, int band_w) {
     __shared__ unsigned long long s_l1[512];
     __shared__ unsigned long long s_l2[8];
+    __shared__ float s_mats[128 * 14];
+    __shared__ float s_mats_x[128 * 8];
+    __shared__ float s_cs[4][64];          // per wave (= 8x8 pixel tile): cos / sin of the 32 tap angles
+    __shared__ uint16_t s_off[32][256];    // per tap, per thread: the tap's pixel offset
     for (int i = threadIdx.x; i < 512; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
     if (threadIdx.x < 8) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
-    __syncthreads();
+    for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
+    for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) s_mats_x[i] = gb.mats_x[i];
     LdsPyramid P;
     P.l0 = sc.pyr.l0; P.l1 = s_l1; P.l2 = s_l2;
-    // 16x16 pixel tile per workgroup = four 8x8 wave tiles
+    SceneData scl = sc;
+    scl.mats = s_mats;
+    GrisBuffers gbl = gb;
+    gbl.mats_x = s_mats_x;
+    // 16x16 pixel tile per workgroup = four 8x8 wave tiles.  Workgroups go to the 8 XCDs round robin: XCD k takes the
+    // k-th vertical band of tiles, row by row, so that the tiles resident on one XCD at a time are neighbours and their
+    // 64x64-pixel tap windows overlap in that XCD's L2.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bx = xcd * band_w + slot % band_w, by = slot / band_w;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int u = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int v = r0 + blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int u = bx * 16 + (wave & 1) * 8 + (lane & 7);
+    const int v = r0 + by * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (lane < 32) gris_tap_cs(u, v, 0, lane, s_cs[wave]);
+    __syncthreads();
+    GrisTaps taps;
+    taps.cs = s_cs[wave]; taps.off = &s_off[0][threadIdx.x]; taps.off_stride = 256;
     TraceStats ts;
     stats_zero(ts);
-    if (u < fp.W && v < r1) gris_pixel(fp, sc, P, gb, u, v, 0, 24.0f, 32, 1, ts);
+    if (bx < tiles_x && u < fp.W && v < r1) gris_pixel(fp, scl, P, gbl, taps, u, v, 0, 24.0f, 32, 1, ts);
     if (INSTR) flush_stats(ts, sc.counters);
 }
 
@@ -655,9 +672,10 @@ hipError_t launch_mat_derived(hipStream_t st, const float* mats, float* mats_x) 
 }
 hipError_t launch_gris(hipStream_t st, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1) {
     hipLaunchKernelGGL(k_gris_prepare, dim3((fp.W + 63) / 64, (fp.row1 - fp.row0 + 3) / 4), dim3(256), 0, st, fp, gb);
-    dim3 g((fp.W + 15) / 16, (r1 - r0 + 15) / 16), b(256);
-    if (instr) hipLaunchKernelGGL((k_gris<true>), g, b, 0, st, fp, sc, gb, r0, r1);
-    else hipLaunchKernelGGL((k_gris<false>), g, b, 0, st, fp, sc, gb, r0, r1);
+    const int tiles_x = (fp.W + 15) / 16, tiles_y = (r1 - r0 + 15) / 16, band_w = (tiles_x + 7) / 8;
+    dim3 g(8 * band_w * tiles_y), b(256);
+    if (instr) hipLaunchKernelGGL((k_gris<true>), g, b, 0, st, fp, sc, gb, r0, r1, tiles_x, band_w);
+    else hipLaunchKernelGGL((k_gris<false>), g, b, 0, st, fp, sc, gb, r0, r1, tiles_x, band_w);
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }

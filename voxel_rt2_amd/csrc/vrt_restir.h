@@ -157,7 +157,8 @@ VRT_DEV void store_mat_derived(float* mats_x, int id, const MatDerived& x) {
 // the destination of every neighbour's shift, is set up once per pixel instead of once per tap)
 // `rc_ty` is the bitangent of the sample's reconnection vertex (ortho_basis of rc_normal, which does not depend on the
 // destination), `mats_x` the per-material-id table of mat_derive().
-VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const float* mats_x, f3 dst_pos, const Surf& ds,
+// `dsc` = surf_shared(ds, ...) with at least the groups of lobe src.z.lobes % 10.
+VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const float* mats_x, f3 dst_pos, const Surf& ds, const SurfShared& dsc,
                           const Reservoir& src, f3 rc_ty, f3& out_d, f3& out_s, float& out_jac, TraceStats& ts) {
     const bool escape = near_zero3(src.z.rc_normal);
     const bool last = near_zero3(src.z.rc_incident_dir);
@@ -173,20 +174,25 @@ VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const floa
     if (!escape) {
         Surf rc;
         surf_set(rc, rc_mat, load_mat_derived(mats_x, rc_id), src.z.rc_normal, -to_rc, cross3(src.z.rc_normal, rc_ty), rc_ty);
+        // two directions (the path's continuation and its sun sample) with their pdfs at one vertex: bsdf_eval_pdf
+        const int rl = src.z.lobes / 10;
+        const SurfShared rcc = surf_shared(rc, nee_vis || (!last && lobe_has(rl, LOBE_DIFFUSE)), nee_vis || (!last && lobe_has(rl, LOBE_SPEC)),
+                                           nee_vis || (!last && lobe_has(rl, LOBE_CLEARCOAT)));
         if (!last) {
             f3 bd, bs;
-            eval_lobes(rc, src.z.rc_incident_dir, src.z.lobes / 10, bd, bs);
+            float dst_rc_pdf;
+            bsdf_eval_pdf(rc, rcc, src.z.rc_incident_dir, rl, PDF_LOBE, bd, bs, dst_rc_pdf);
             f3 rc_brdf = (bd + bs) * dm_saturate(dot3(src.z.rc_normal, src.z.rc_incident_dir));
-            float dst_rc_pdf = pdf_lobe(rc, src.z.rc_incident_dir, src.z.lobes / 10);
             float lp = cone_pdf(fp.light_cos_max, dot3(fp.light_dir, src.z.rc_incident_dir));
             float w = power_heuristic(dst_rc_pdf, lp * (nee_vis ? 1.0f : 0.0f));
             contrib = contrib + firefly(w * rc_brdf / dst_rc_pdf * src.z.rc_incident_L);
         }
         if (nee_vis) {
             f3 bd, bs;
-            eval_lobes(rc, src.z.rc_nee_dir, LOBE_ALL, bd, bs);
+            float pdf_nee;
+            bsdf_eval_pdf(rc, rcc, src.z.rc_nee_dir, LOBE_ALL, PDF_ALL, bd, bs, pdf_nee);
             f3 nee_brdf = (bd + bs) * dm_saturate(dot3(src.z.rc_normal, src.z.rc_nee_dir));
-            float w = power_heuristic(cone_pdf(fp.light_cos_max, 1.0f), pdf_all(rc, src.z.rc_nee_dir));
+            float w = power_heuristic(cone_pdf(fp.light_cos_max, 1.0f), pdf_nee);
             f3 sky_t = mk3(1.0f);
             if (fp.use_sky == 1) { sky_t = sky_transmittance(sc.sky, src.z.rc_nee_dir); ts.sky_lookups += 1u; }
             contrib = contrib + firefly(w * nee_brdf * sky_t * fp.light_weight * fp.light_color);
@@ -197,7 +203,8 @@ VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const floa
     contrib = contrib + ((rc_id != 2) ? mk3(0.0f) : rc_mat.base);
 
     f3 pd, ps;
-    eval_lobes(ds, to_rc, src.z.lobes % 10, pd, ps);
+    float no_pdf;
+    bsdf_eval_pdf(ds, dsc, to_rc, src.z.lobes % 10, PDF_NONE, pd, ps, no_pdf);
     const float c = dm_saturate(dot3(dst_normal, to_rc));
     pd = pd * c;
     ps = ps * c;
@@ -289,16 +296,32 @@ VRT_DEV void gris_load_src(Reservoir& r, f3& rc_ty, const GrisSrc& s) {
     rc_ty = s.rc_ty;
 }
 
-// pathtracer.py:883-906: tap i of the golden-angle spiral around (u, v); false for the centre itself and for taps
-// outside the image (the reference reads out of bounds there)
-VRT_DEV bool gris_tap(const FrameParams& fp, int u, int v, int i, float angle_shift, float radius_shift, float max_radius,
-                      int max_taps, int& tx, int& ty) {
+// pathtracer.py:876-891: the taps lie on a golden-angle spiral whose phase is hashed from the pixel's 8x8 tile (pass 0),
+// so the angle, sine and cosine of tap i are the same for all 64 pixels of a tile: worked out once per tile into
+// cs[2i] = cos, cs[2i+1] = sin.  Only the radius (one draw per pixel) differs inside a tile.
+VRT_DEV float gris_angle_shift(int u, int v, int pass_id) {
+    const uint32_t sx = (pass_id == 0) ? ((uint32_t)u >> 3) : 2u, sy = (pass_id == 0) ? ((uint32_t)v >> 3) : 2u;
+    const uint32_t hs = hash3(sx, sy, 0u + (uint32_t)pass_id);
+    return (float)((hs & 0x007FFFFFu) | 0x3F800000u) / 4294967295.0f * DM_PI;
+}
+VRT_DEV void gris_tap_cs(int u, int v, int pass_id, int i, float* cs) {
     const float golden = 2.399963229728f;
-    float angle = ((float)i + angle_shift) * golden;
+    float angle = ((float)i + gris_angle_shift(u, v, pass_id)) * golden;
+    dm_sincos(angle, &cs[2 * i + 1], &cs[2 * i]);
+}
+// Scratch of one pixel's tap loop: the tile's table above, and one 16-bit slot per tap where the first loop leaves the
+// tap's pixel offset for the two expensive loops (slot of tap i at off[i * off_stride]).
+struct GrisTaps {
+    const float* cs;
+    uint16_t* off;
+    int off_stride;
+};
+// pathtracer.py:883-906: offset of tap i; false for the centre itself and for taps outside the image (the reference
+// reads out of bounds there)
+VRT_DEV bool gris_tap(const FrameParams& fp, const GrisTaps& taps, int u, int v, int i, float radius_shift, float max_radius,
+                      int max_taps, int& tx, int& ty) {
     float rad = dm_sqrt(((float)i + radius_shift) / (float)max_taps) * max_radius;
-    float sa, ca;
-    dm_sincos(angle, &sa, &ca);
-    int ox = dm_f2i(ca * rad), oy = dm_f2i(sa * rad);
+    int ox = dm_f2i(taps.cs[2 * i] * rad), oy = dm_f2i(taps.cs[2 * i + 1] * rad);
     tx = u + ox; ty = v + oy;
     if (ox == 0 && oy == 0) return false;
     return !(tx < 0 || ty < 0 || tx >= fp.W || ty >= fp.H);
@@ -306,7 +329,7 @@ VRT_DEV bool gris_tap(const FrameParams& fp, int u, int v, int i, float angle_sh
 
 // pathtracer.py:815-989, called as spatial_GRIS(0, 24.0, 32, 1) (:1313)
 template <class PyrT>
-VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& P, const GrisBuffers& gb, int u, int v,
+VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& P, const GrisBuffers& gb, const GrisTaps& taps, int u, int v,
                         int pass_id, float max_radius, int max_taps, int pass_total, TraceStats& ts) {
     const int idx = (v - fp.row0) * fp.W + u;
     if (outside_render_area(fp, (float)u, (float)v)) {
@@ -319,9 +342,6 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     }
     dm_rng rng = dm_rng_init(fp.seed, fp.frame, (uint32_t)(v * fp.W + u), 1u);
     (void)dm_rng_f32(&rng);  // start_index draw (:827), value unused
-    const uint32_t sx = (pass_id == 0) ? ((uint32_t)u >> 3) : 2u, sy = (pass_id == 0) ? ((uint32_t)v >> 3) : 2u;
-    const uint32_t hs = hash3(sx, sy, 0u + (uint32_t)pass_id);
-    const float angle_shift = (float)((hs & 0x007FFFFFu) | 0x3F800000u) / 4294967295.0f * DM_PI;
     const float radius_shift = dm_rng_f32(&rng);
 
     Reservoir center, outr;
@@ -343,6 +363,8 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     const Material cmat = material_from_bits(sc.mats, cg.mat, cmat_id);
     Surf cds;  // the centre pixel's shading frame (pathtracer.py:731-732 with dst = centre)
     surf_set(cds, cmat, load_mat_derived(gb.mats_x, cmat_id), cn1, cg.v, cross3(cn1, cg.ty), cg.ty);
+    const SurfShared cdsc = surf_shared(cds, true, true, true);   // destination of every neighbour's sample, whatever its lobe
+    const int cl = center.z.lobes % 10;                           // the lobe the centre's sample leaves every neighbour's vertex by
     int valid = 0;
     float canonical_mis = 1.0f;
     f3 chosen_d = mk3(0.0f), chosen_s = mk3(0.0f);
@@ -358,7 +380,8 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     unsigned accepted = 0u;  // max_taps <= 32
     for (int i = 0; i < max_taps; i++) {
         int tx, ty;
-        if (!gris_tap(fp, u, v, i, angle_shift, radius_shift, max_radius, max_taps, tx, ty)) continue;
+        if (!gris_tap(fp, taps, u, v, i, radius_shift, max_radius, max_taps, tx, ty)) continue;
+        taps.off[i * taps.off_stride] = (uint16_t)((tx - u + 128) | ((ty - v + 128) << 8));  // |offset| <= max_radius < 128
         const GrisGeo* ng = &gb.geo[(ty - fp.row0) * fp.W + tx];
         const f3 nn1 = ng->n;
         const float ndist = ng->dist;
@@ -367,8 +390,8 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     }
     for (unsigned m = accepted; m != 0u; m &= m - 1u) {
         const int i = __builtin_ctz(m);
-        int tx, ty;
-        (void)gris_tap(fp, u, v, i, angle_shift, radius_shift, max_radius, max_taps, tx, ty);
+        const int packed = taps.off[i * taps.off_stride];
+        const int tx = u + (packed & 255) - 128, ty = v + (packed >> 8) - 128;
         const GrisGeo ng = gb.geo[(ty - fp.row0) * fp.W + tx];
         const float nb_M = ng.M;
         int nmat_id;
@@ -377,7 +400,8 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         float cjac;
         Surf nds;
         surf_set(nds, nmat, load_mat_derived(gb.mats_x, nmat_id), ng.n, ng.v, cross3(ng.n, ng.ty), ng.ty);
-        shift_sample(fp, sc, gb.mats_x, ng.x1, nds, center, center_rc_ty, cd, cs, cjac, ts);
+        const SurfShared ndsc = surf_shared(nds, lobe_has(cl, LOBE_DIFFUSE), lobe_has(cl, LOBE_SPEC), lobe_has(cl, LOBE_CLEARCOAT));
+        shift_sample(fp, sc, gb.mats_x, ng.x1, nds, ndsc, center, center_rc_ty, cd, cs, cjac, ts);
         float c_p_hat = lum(cd + cs) * cjac;
         float cw = c_p_hat * nb_M;
         cw /= c_p_hat * nb_M + lum(center.z.F) * center.M / (float)max_taps;
@@ -385,14 +409,14 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     }
     for (unsigned m = accepted; m != 0u; m &= m - 1u) {
         const int i = __builtin_ctz(m);
-        int tx, ty;
-        (void)gris_tap(fp, u, v, i, angle_shift, radius_shift, max_radius, max_taps, tx, ty);
+        const int packed = taps.off[i * taps.off_stride];
+        const int tx = u + (packed & 255) - 128, ty = v + (packed >> 8) - 128;
         Reservoir nb;
         f3 nb_rc_ty;
         gris_load_src(nb, nb_rc_ty, gb.src[(ty - fp.row0) * fp.W + tx]);
         f3 sd, ss;
         float jac;
-        shift_sample(fp, sc, gb.mats_x, cx1, cds, nb, nb_rc_ty, sd, ss, jac, ts);
+        shift_sample(fp, sc, gb.mats_x, cx1, cds, cdsc, nb, nb_rc_ty, sd, ss, jac, ts);
 
         float p_hat = lum(sd + ss);
         float p_hat_n = p_hat / jac;
