@@ -249,7 +249,7 @@ int emu_accumulate(Emu* c, int n_samples) {
             if (c->mats_x.empty()) derive_materials(c);
             gb.geo = c->gris_geo.data(); gb.src = c->gris_src.data(); gb.mats_x = c->mats_x.data();
             for (int v = fp.row0; v < fp.row1; v++)
-                for (int u = 0; u < fp.W; u++) gris_prepare_pixel(fp, gb, u, v);
+                for (int u = 0; u < fp.W; u++) gris_prepare_pixel(fp, sc, gb, u, v);
             GlobalPyramid P;
             P.p = sc.pyr;
             int g0 = c->own0 - 2 < c->buf0 ? c->buf0 : c->own0 - 2, g1 = c->own1 + 2 > c->buf1 ? c->buf1 : c->own1 + 2;

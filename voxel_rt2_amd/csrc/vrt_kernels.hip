@@ -527,10 +527,10 @@ __global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES) void k_gris(FrameParams fp
 }
 
 // once per pixel of every row the launch holds: the records k_gris reads ~32 times per pixel (vrt_restir.h)
-__global__ __launch_bounds__(256) void k_gris_prepare(FrameParams fp, GrisBuffers gb) {
+__global__ __launch_bounds__(256) void k_gris_prepare(FrameParams fp, SceneData sc, GrisBuffers gb) {
     const int u = blockIdx.x * 64 + (threadIdx.x & 63);
     const int v = fp.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (u < fp.W && v < fp.row1) gris_prepare_pixel(fp, gb, u, v);
+    if (u < fp.W && v < fp.row1) gris_prepare_pixel(fp, sc, gb, u, v);
 }
 __global__ void k_mat_derived(const float* mats, float* mats_x) {
     const int id = threadIdx.x;
@@ -671,7 +671,7 @@ hipError_t launch_mat_derived(hipStream_t st, const float* mats, float* mats_x) 
     return hipSuccess;
 }
 hipError_t launch_gris(hipStream_t st, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1) {
-    hipLaunchKernelGGL(k_gris_prepare, dim3((fp.W + 63) / 64, (fp.row1 - fp.row0 + 3) / 4), dim3(256), 0, st, fp, gb);
+    hipLaunchKernelGGL(k_gris_prepare, dim3((fp.W + 63) / 64, (fp.row1 - fp.row0 + 3) / 4), dim3(256), 0, st, fp, sc, gb);
     const int tiles_x = (fp.W + 15) / 16, tiles_y = (r1 - r0 + 15) / 16, band_w = (tiles_x + 7) / 8;
     dim3 g(8 * band_w * tiles_y), b(256);
     if (instr) hipLaunchKernelGGL((k_gris<true>), g, b, 0, st, fp, sc, gb, r0, r1, tiles_x, band_w);

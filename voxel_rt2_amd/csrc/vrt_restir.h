@@ -156,10 +156,11 @@ VRT_DEV void store_mat_derived(float* mats_x, int id, const MatDerived& x) {
 // (normal, material, view direction toward the camera -- built by the caller so the centre pixel's frame, which is
 // the destination of every neighbour's shift, is set up once per pixel instead of once per tap)
 // `rc_ty` is the bitangent of the sample's reconnection vertex (ortho_basis of rc_normal, which does not depend on the
-// destination), `mats_x` the per-material-id table of mat_derive().
+// destination), `src_sky_t` the sky transmittance toward its sun sample (GrisSrc), `mats_x` the per-material-id table of
+// mat_derive().
 // `dsc` = surf_shared(ds, ...) with at least the groups of lobe src.z.lobes % 10.
 VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const float* mats_x, f3 dst_pos, const Surf& ds, const SurfShared& dsc,
-                          const Reservoir& src, f3 rc_ty, f3& out_d, f3& out_s, float& out_jac, TraceStats& ts) {
+                          const Reservoir& src, f3 rc_ty, f3 src_sky_t, f3& out_d, f3& out_s, float& out_jac, TraceStats& ts) {
     const bool escape = near_zero3(src.z.rc_normal);
     const bool last = near_zero3(src.z.rc_incident_dir);
     const bool nee_vis = !near_zero3(src.z.rc_nee_dir);
@@ -194,7 +195,7 @@ VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const floa
             f3 nee_brdf = (bd + bs) * dm_saturate(dot3(src.z.rc_normal, src.z.rc_nee_dir));
             float w = power_heuristic(cone_pdf(fp.light_cos_max, 1.0f), pdf_nee);
             f3 sky_t = mk3(1.0f);
-            if (fp.use_sky == 1) { sky_t = sky_transmittance(sc.sky, src.z.rc_nee_dir); ts.sky_lookups += 1u; }
+            if (fp.use_sky == 1) { sky_t = src_sky_t; ts.sky_lookups += 1u; }  // counted where the reference looks it up
             contrib = contrib + firefly(w * nee_brdf * sky_t * fp.light_weight * fp.light_color);
         }
     } else {
@@ -233,7 +234,7 @@ VRT_DEV uint32_t hash3(uint32_t x, uint32_t y, uint32_t z) {  // math_utils.py:2
 // What the spatial-reuse kernel needs of a pixel each of the ~32 times it is somebody's neighbour, worked out once per
 // pixel by gris_prepare_pixel() instead (same expressions, so the same bits): the primary vertex as the destination of a
 // shift (GrisGeo, pathtracer.py:896-912 + 731-732) and the decoded reservoir as the source of one (GrisSrc,
-// reservoir.py:126-141).  16-byte aligned so that a tap is four / seven 128-bit loads.
+// reservoir.py:126-141).  16-byte aligned so that a tap is four / eight 128-bit loads.
 struct alignas(16) GrisGeo {
     f3 n; float dist;        // g-buffer normal; distance of x1 from the camera  (the two the acceptance test reads)
     f3 x1; uint32_t mat;     // primary vertex from the g-buffer depth; packed material
@@ -248,6 +249,7 @@ struct alignas(16) GrisSrc {
     f3 rc_incident_L; uint32_t rc_mat_info;
     f3 rc_nee_dir; uint32_t pad0;
     f3 rc_ty; uint32_t pad1;  // bitangent of ortho_basis(rc_normal)
+    f3 sky_t; uint32_t pad2;  // sky transmittance toward rc_nee_dir (atmos.py:117-131): depends on the sample alone
 };
 
 struct GrisBuffers {
@@ -266,7 +268,7 @@ struct GrisBuffers {
 };
 
 // once per pixel of every row the launch holds (the rows it renders and their halo)
-VRT_DEV void gris_prepare_pixel(const FrameParams& fp, const GrisBuffers& gb, int u, int v) {
+VRT_DEV void gris_prepare_pixel(const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int u, int v) {
     const int idx = (v - fp.row0) * fp.W + u;
     GrisGeo g;
     g.n = oct_decode(gb.gb_normal[idx]);
@@ -287,13 +289,18 @@ VRT_DEV void gris_prepare_pixel(const FrameParams& fp, const GrisBuffers& gb, in
     s.rc_incident_dir = r.z.rc_incident_dir; s.lobes = r.z.lobes; s.rc_incident_L = r.z.rc_incident_L;
     s.rc_mat_info = r.z.rc_mat_info; s.rc_nee_dir = r.z.rc_nee_dir; s.pad0 = 0u; s.pad1 = 0u;
     ortho_basis(r.z.rc_normal, tx, s.rc_ty);
+    // every shift of this sample that sees its sun sample weighs it by the sky's transmittance toward the sun sample
+    // (pathtracer.py:770-772): one table lookup here instead of one per shift (~60 per pixel)
+    s.sky_t = (fp.use_sky == 1 && !near_zero3(r.z.rc_nee_dir)) ? sky_transmittance(sc.sky, r.z.rc_nee_dir) : mk3(1.0f);
+    s.pad2 = 0u;
     gb.src[idx] = s;
 }
-VRT_DEV void gris_load_src(Reservoir& r, f3& rc_ty, const GrisSrc& s) {
+VRT_DEV void gris_load_src(Reservoir& r, f3& rc_ty, f3& sky_t, const GrisSrc& s) {
     r.z.F = s.F; r.M = s.M; r.z.rc_pos = s.rc_pos; r.weight = s.weight; r.z.rc_normal = s.rc_normal; r.z.jac = s.jac;
     r.z.rc_incident_dir = s.rc_incident_dir; r.z.lobes = s.lobes; r.z.rc_incident_L = s.rc_incident_L;
     r.z.rc_mat_info = s.rc_mat_info; r.z.rc_nee_dir = s.rc_nee_dir;
     rc_ty = s.rc_ty;
+    sky_t = s.sky_t;
 }
 
 // pathtracer.py:876-891: the taps lie on a golden-angle spiral whose phase is hashed from the pixel's 8x8 tile (pass 0),
@@ -345,8 +352,8 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     const float radius_shift = dm_rng_f32(&rng);
 
     Reservoir center, outr;
-    f3 center_rc_ty;
-    gris_load_src(center, center_rc_ty, gb.src[idx]);
+    f3 center_rc_ty, center_sky_t;
+    gris_load_src(center, center_rc_ty, center_sky_t, gb.src[idx]);
     reservoir_init(outr);
 
     const GrisGeo cg = gb.geo[idx];
@@ -401,7 +408,7 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         Surf nds;
         surf_set(nds, nmat, load_mat_derived(gb.mats_x, nmat_id), ng.n, ng.v, cross3(ng.n, ng.ty), ng.ty);
         const SurfShared ndsc = surf_shared(nds, lobe_has(cl, LOBE_DIFFUSE), lobe_has(cl, LOBE_SPEC), lobe_has(cl, LOBE_CLEARCOAT));
-        shift_sample(fp, sc, gb.mats_x, ng.x1, nds, ndsc, center, center_rc_ty, cd, cs, cjac, ts);
+        shift_sample(fp, sc, gb.mats_x, ng.x1, nds, ndsc, center, center_rc_ty, center_sky_t, cd, cs, cjac, ts);
         float c_p_hat = lum(cd + cs) * cjac;
         float cw = c_p_hat * nb_M;
         cw /= c_p_hat * nb_M + lum(center.z.F) * center.M / (float)max_taps;
@@ -412,11 +419,11 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         const int packed = taps.off[i * taps.off_stride];
         const int tx = u + (packed & 255) - 128, ty = v + (packed >> 8) - 128;
         Reservoir nb;
-        f3 nb_rc_ty;
-        gris_load_src(nb, nb_rc_ty, gb.src[(ty - fp.row0) * fp.W + tx]);
+        f3 nb_rc_ty, nb_sky_t;
+        gris_load_src(nb, nb_rc_ty, nb_sky_t, gb.src[(ty - fp.row0) * fp.W + tx]);
         f3 sd, ss;
         float jac;
-        shift_sample(fp, sc, gb.mats_x, cx1, cds, cdsc, nb, nb_rc_ty, sd, ss, jac, ts);
+        shift_sample(fp, sc, gb.mats_x, cx1, cds, cdsc, nb, nb_rc_ty, nb_sky_t, sd, ss, jac, ts);
 
         float p_hat = lum(sd + ss);
         float p_hat_n = p_hat / jac;
