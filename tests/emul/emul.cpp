@@ -331,4 +331,51 @@ int emu_get_stats(Emu* c, vrt_stats* s) {
     s->closest_hits = c->ts.closest_hits; s->sky_lookups = c->ts.sky_lookups;
     return 0;
 }
+
+// The spatial-reuse kernel evaluates the BSDF through bsdf_eval_pdf() with per-vertex shared terms and a per-material
+// table (vrt_bsdf.h); the render kernels through eval_lobes() / pdf_lobe() / pdf_all() / surf_init().  Both must give
+// the same bits: random materials (all parameters live), normals, view and light directions on either side of the
+// surface, every lobe code.  Returns the number of mismatching cases.
+int emu_bsdf_selftest(int n, uint32_t seed) {
+    dm_rng rng = dm_rng_init(seed, 0u, 0u, 7u);
+    auto rnd = [&]() { return dm_rng_f32(&rng); };
+    auto unit = [&]() { f3 v = mk3(rnd() * 2.0f - 1.0f, rnd() * 2.0f - 1.0f, rnd() * 2.0f - 1.0f); return norm3(v + mk3(1e-3f, 0.0f, 0.0f)); };
+    auto same = [](float a, float b) { return dm_f2u(a) == dm_f2u(b) || (a != a && b != b); };
+    int bad = 0;
+    for (int k = 0; k < n; k++) {
+        Material m;
+        const bool plain = (k & 3) == 0;  // a quarter of the cases with the defaults' zeros (sheen, clearcoat, metallic ...)
+        m.base = mk3(rnd(), rnd(), rnd());
+        if ((k & 15) == 5) m.base = mk3(0.0f);
+        m.subsurface = plain ? 0.0f : rnd(); m.metallic = plain ? 0.0f : rnd(); m.specular = rnd(); m.specular_tint = plain ? 0.0f : rnd();
+        m.roughness = (k & 7) == 3 ? 0.0f : rnd(); m.anisotropic = plain ? 0.0f : rnd(); m.sheen = plain ? 0.0f : rnd(); m.sheen_tint = rnd();
+        m.clearcoat = plain ? 0.0f : rnd(); m.clearcoat_gloss = rnd(); m.ior_minus_one = 0.0f;
+        const f3 n1 = unit(), v = unit(), l = unit();
+        float table[8];
+        store_mat_derived(table, 0, mat_derive(m));
+        Surf a, b;
+        surf_init(a, m, n1, v);
+        f3 tx, ty;
+        ortho_basis(n1, tx, ty);
+        surf_set(b, m, load_mat_derived(table, 0), n1, v, cross3(n1, ty), ty);
+        const int lobes[6] = {LOBE_DIFFUSE, LOBE_SPEC, LOBE_CLEARCOAT, LOBE_ALL, 5, -3};
+        for (int q = 0; q < 6; q++) {
+            const int lobe = lobes[q];
+            f3 rd, rs, xd, xs;
+            eval_lobes(a, l, lobe, rd, rs);
+            const float rp_lobe = pdf_lobe(a, l, lobe), rp_all = pdf_all(a, l);
+            for (int mode = 0; mode < 3; mode++) {
+                const bool all = mode == PDF_ALL;
+                const SurfShared c = surf_shared(b, all || lobe_has(lobe, LOBE_DIFFUSE), all || lobe_has(lobe, LOBE_SPEC), all || lobe_has(lobe, LOBE_CLEARCOAT));
+                float xp;
+                bsdf_eval_pdf(b, c, l, lobe, mode, xd, xs, xp);
+                bool ok = same(rd.x, xd.x) && same(rd.y, xd.y) && same(rd.z, xd.z) && same(rs.x, xs.x) && same(rs.y, xs.y) && same(rs.z, xs.z);
+                if (mode == PDF_LOBE) ok = ok && same(rp_lobe, xp);
+                if (mode == PDF_ALL) ok = ok && same(rp_all, xp);
+                if (!ok) bad++;
+            }
+        }
+    }
+    return bad;
+}
 }

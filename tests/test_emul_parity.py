@@ -121,3 +121,13 @@ def test_sky_lookup():
     a, b = o.fetch_hdr(), e.fetch_hdr()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert o.stats()["sky_lookups"] == e.stats()["sky_lookups"] > 0
+
+
+def test_spatial_reuse_bsdf_path_equals_render_bsdf_path():
+    """bsdf_eval_pdf + surf_shared + the material-derived table (k_gris) against eval_lobes / pdf_lobe / pdf_all /
+    surf_init (render kernels): same bits for random materials, directions and lobe codes."""
+    import ctypes as C
+    lib = emu.lib()
+    lib.emu_bsdf_selftest.argtypes = [C.c_int, C.c_uint32]
+    lib.emu_bsdf_selftest.restype = C.c_int
+    assert lib.emu_bsdf_selftest(20000, 11) == 0
