@@ -98,15 +98,25 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the renderer has no CPU path")
+    # VRT_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a one-GPU box -- every rank on device 0, collectives over
+    # gloo with host staging instead of RCCL.  Exercises the sharding, rebalancing, gather and reporting logic; its
+    # numbers mean nothing.
+    rehearse = os.environ.get("VRT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    coll_dev = "cpu" if rehearse else "cuda"
 
     from voxel_rt2_amd import parallel
     mat, rgb, params = scenes.scene_s1(0)
     lib = _lib.load()
-    stream = torch.cuda.Stream()  # rendering, tile copy and the RCCL gather are all ordered on this one stream
+    stream = torch.cuda.Stream()  # the context's stream: temporal passes and the tile copy (render launches go to the library's own streams)
 
     def make_session(rows):
         cfg = host.make_config(WIDTH, HEIGHT, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=MAX_DEPTH,
@@ -127,7 +137,7 @@ def main():
         lib.vrt_reset_stats(C.c_void_p(sess._ctx))
         sess.accumulate(SPP_PER_STEP)
         st0 = sess.stats()
-        mine = torch.tensor([st0["render_ms"] + st0["temporal_ms"]], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([st0["render_ms"] + st0["temporal_ms"]], dtype=torch.float64, device=coll_dev)
         allc = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allc, mine)
         bounds = parallel.rebalance_rows(bounds, [float(t.item()) for t in allc], HEIGHT)
@@ -139,20 +149,43 @@ def main():
         os.environ["VRT_OVERLAP"] = user_overlap
     rows = bounds[rank]
 
-    # gather plumbing: equal-sized tiles (padded to the tallest tile), torch owns the staging tensors
+    # gather plumbing: equal-sized tiles (padded to the tallest tile), torch owns the staging tensors.  The gather runs on
+    # its own stream behind an event, from one of two staging tiles, so that the next step's temporal pass (same stream as
+    # the tile copy) does not queue behind a collective that waits for the slowest rank.
     max_rows = max(b - a for a, b in bounds)
-    tile = torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device="cuda")
-    gathered = [torch.zeros_like(tile) for _ in range(world)] if (world > 1 and rank == 0) else None
+    tiles = [torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+    gathered = [torch.zeros_like(tiles[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
+    host_gathered = [torch.zeros_like(tiles[0], device="cpu") for _ in range(world)] if (rehearse and gathered is not None) else None
+    gather_stream = torch.cuda.Stream() if world > 1 else None
+    tile_free = [None, None]   # recorded on gather_stream when the gather that read tiles[j] is done
+    step_no = [0]
 
     def step():
+        j = step_no[0] & 1
+        step_no[0] += 1
         with torch.cuda.stream(stream):
             sess.accumulate(SPP_PER_STEP)
             if world > 1:
-                sess.fetch_hdr_device_async(tile.data_ptr())  # D2D, queued behind the kernels
-                dist.gather(tile, gathered, dst=0)
+                if tile_free[j] is not None:
+                    stream.wait_event(tile_free[j])
+                sess.fetch_hdr_device_async(tiles[j].data_ptr())  # D2D, queued behind the kernels
+                ready = stream.record_event()
+        if world > 1:
+            with torch.cuda.stream(gather_stream):
+                gather_stream.wait_event(ready)
+                if rehearse:
+                    dist.gather(tiles[j].cpu(), host_gathered, dst=0)
+                    if rank == 0:
+                        for g, h in zip(gathered, host_gathered):
+                            g.copy_(h)
+                else:
+                    dist.gather(tiles[j], gathered, dst=0)
+                tile_free[j] = gather_stream.record_event()
 
     def fence():
         stream.synchronize()
+        if gather_stream is not None:
+            gather_stream.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -168,10 +201,26 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = sess.stats()
+
+    if rehearse and world > 1 and rank == 0:
+        # rehearsal only: the frame assembled from the gathered tiles equals an unsharded render of the same passes
+        full = np.concatenate([gathered[r][: bounds[r][1] - bounds[r][0]].cpu().numpy() for r in range(world)], axis=0)
+        cfg1 = host.make_config(WIDTH, HEIGHT, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=MAX_DEPTH,
+                                seed=SEED, device=local_rank)
+        one = NativeSession(lib, "vrt_", cfg1)
+        setup_session(one, mat, rgb, params)
+        for _ in range(args.warmup + args.steps):
+            one.accumulate(SPP_PER_STEP)
+        ref = one.fetch_hdr()
+        one.close()
+        same = np.array_equal(full.view(np.uint32), ref.view(np.uint32))
+        print(f"[rehearsal] gathered frame == unsharded frame: {same}", file=sys.stderr, flush=True)
+        if not same:
+            raise SystemExit("rehearsal: gathered frame differs from the unsharded render")
 
     # algorithmic bytes of the dominant kernel: one untimed instrumented pass counts what a path does
     lib.vrt_set_instrumented(C.c_void_p(sess._ctx), 1)
@@ -198,7 +247,7 @@ def main():
         # the render stage runs the pooled schedule (k_render_pool) unless VRT_RENDER=fused asks for the fused one
         render_kernel = "k_render" if os.environ.get("VRT_RENDER") == "fused" else "k_render_pool"
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and world == 1:  # measured on the one-GPU launch (whole frame); a tile's launch moves less
             try:
                 traffic = json.load(open(tfile)).get(f"{render_kernel}_bytes_per_launch")
             except Exception:
