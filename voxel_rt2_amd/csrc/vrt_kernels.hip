@@ -6,7 +6,9 @@
 //                                                         a wave owns 128 path records in LDS and runs them stage by
 //                                                         stage (WALK / SHADE / ESCAPE / BEGIN); default without ReSTIR
 //   k_render<RESTIR, INSTR>                               persistent wave64 path tracer, one path per lane (vrt_path.h)
-//   k_gris                                                ReSTIR spatial reuse
+//   k_gris_prepare / k_gris                               ReSTIR spatial reuse: per-pixel records (decoded sample, shading
+//                                                         basis), then 32 taps x 2 reconnection shifts per pixel
+//   k_mat_derived                                         per-material-id part of a shading point (after material uploads)
 //   k_temporal                                            fused temporal accumulation -> HDR (sized to run beside
 //                                                         the next render launch, see vrt_api.hip)
 //   k_tonemap                                             LDR presentation
