@@ -22,6 +22,7 @@ CASES = [
     dict(name="s6_sky_clouds_1080p_d8_norestir", scene="s6", W=1920, H=1080, depth=8, spp=4, steps=5, sky_res=3840),
     dict(name="sunlit_restir_1080p_d8", scene="sunlit", W=1920, H=1080, depth=8, spp=4, steps=5, restir=True),
     dict(name="s6_nosky_restir_1080p_d8", scene="s6", W=1920, H=1080, depth=8, spp=4, steps=5, restir=True),
+    dict(name="s6_nosky_plain_1080p_d8", scene="s6", W=1920, H=1080, depth=8, spp=4, steps=5),
     # one rank's share of an 8- and a 2-GPU run of config 2 (rows through the middle of the picture)
     dict(name="shard_1of8_config2", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=20, rows=(472, 607)),
     dict(name="shard_1of2_config2", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=20, rows=(0, 540)),
