@@ -1,0 +1,29 @@
+"""bench.py's N > 1 path on the one-GPU box: two ranks on device 0, gloo with host staging in place of RCCL
+(VRT_BENCH_REHEARSE=1).  Rank 0 itself checks that the frame assembled from the gathered row tiles equals an
+unsharded render of the same passes bit for bit; here: the run succeeds, says so, and prints the one JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal():
+    env = dict(os.environ, VRT_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "[rehearsal] gathered frame == unsharded frame: True" in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 2 and out["value"] > 0
+    assert out["cpu_baseline"] is None and out["roofline"]["traffic"] is None
+    assert sum(int(x) for x in out["config"]["sharding"].split("[")[1].split("]")[0].split(",")) == 1080
