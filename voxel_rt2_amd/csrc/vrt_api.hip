@@ -652,8 +652,7 @@ int vrt_fetch_hdr_device_async(vrt_ctx* c, void* device_ptr) {
     HIP_TRY(hipSetDevice(c->device));
     const size_t W = c->cfg.width;
     const char* src = (const char*)c->d_cbuf[c->cidx] + (size_t)(c->own0 - c->buf0) * W * sizeof(f3);
-    if (((uintptr_t)device_ptr & 3u) != 0u) return fail(VRT_E_INVALID, "device pointer must be 4-byte aligned");
-    HIP_TRY(launch_copy(c->stream, src, device_ptr, (size_t)(c->own1 - c->own0) * W * sizeof(f3)));
+    HIP_TRY(hipMemcpyAsync(device_ptr, src, (size_t)(c->own1 - c->own0) * W * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
     return VRT_OK;
 }
 int vrt_set_stream(vrt_ctx* c, void* hip_stream) {

@@ -51,7 +51,6 @@ hipError_t launch_gris(hipStream_t st, bool instr, const FrameParams& fp, const 
 hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1, int n_samples);
 hipError_t launch_tonemap(hipStream_t st, const FrameParams& fp, const f3* hdr, f4* ldr, int r0, int r1);
 hipError_t launch_diag_read(hipStream_t st, unsigned long long* out, int reset);  // -DVRT_DIAG_REGIONS builds only
-hipError_t launch_copy(hipStream_t st, const void* src, void* dst, size_t bytes);  // device to device, whole dwords, as a kernel
 hipError_t launch_detmath_probe(hipStream_t st, int op, int n, const float* a, const float* b, float* out);
 
 // sky precompute (vrt_sky_kernels.hip)

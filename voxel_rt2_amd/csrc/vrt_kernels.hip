@@ -693,25 +693,6 @@ hipError_t launch_tonemap(hipStream_t st, const FrameParams& fp, const f3* hdr, 
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
-// Device-to-device copy of whole dwords as a kernel small enough (a handful of registers, no LDS) to run on CUs that
-// persistent render workgroups occupy: the runtime's own copy path reached ~170 GB/s there and sat on the stream between
-// two temporal passes (vrt_fetch_hdr_device_async, once per step of a multi-GPU run).
-__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-__global__ __launch_bounds__(256) void k_copy4(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n4) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-hipError_t launch_copy(hipStream_t st, const void* src, void* dst, size_t bytes) {  // bytes % 4 == 0, both 4-byte aligned
-    if (bytes == 0) return hipSuccess;
-    const bool wide = (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)bytes) & 15u) == 0u;
-    const size_t n = wide ? bytes / 16 : bytes / 4;
-    const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    if (wide) hipLaunchKernelGGL(k_copy16, dim3(blocks), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, n);
-    else hipLaunchKernelGGL(k_copy4, dim3(blocks), dim3(256), 0, st, (const uint32_t*)src, (uint32_t*)dst, n);
-    VRT_LAUNCH_CHECK();
-    return hipSuccess;
-}
 hipError_t launch_detmath_probe(hipStream_t st, int op, int n, const float* a, const float* b, float* out) {
     hipLaunchKernelGGL(k_detmath_probe, dim3((n + 255) / 256), dim3(256), 0, st, op, n, a, b, out);
     VRT_LAUNCH_CHECK();
