@@ -156,18 +156,19 @@ def main():
     rows = bounds[rank]
 
     # gather plumbing: equal-sized tiles (padded to the tallest tile), torch owns the staging tensors.  The gather runs on
-    # its own stream behind an event, from one of two staging tiles, so that the next step's temporal pass (same stream as
+    # its own stream behind an event, from one of three staging tiles, so that the next step's temporal pass (same stream as
     # the tile copy) does not queue behind a collective that waits for the slowest rank.
     max_rows = max(b - a for a, b in bounds)
-    tiles = [torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+    n_tiles = 3
+    tiles = [torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device="cuda") for _ in range(n_tiles)]
     gathered = [torch.zeros_like(tiles[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
     host_gathered = [torch.zeros_like(tiles[0], device="cpu") for _ in range(world)] if (rehearse and gathered is not None) else None
     gather_stream = torch.cuda.Stream() if world > 1 else None
-    tile_free = [None, None]   # recorded on gather_stream when the gather that read tiles[j] is done
+    tile_free = [None] * n_tiles   # recorded on gather_stream when the gather that read tiles[j] is done
     step_no = [0]
 
     def step():
-        j = step_no[0] & 1
+        j = step_no[0] % n_tiles
         step_no[0] += 1
         with torch.cuda.stream(stream):
             sess.accumulate(SPP_PER_STEP)
