@@ -238,7 +238,15 @@ DM_HD float dm_atan2(float y, float x) {
 }
 
 /* ---- binary16 <-> binary32, round to nearest even ---------------------------------------- */
+/* On the device both conversions are the hardware instruction (v_cvt_f16_f32 / v_cvt_f32_f16: round to nearest even,
+ * subnormal halves kept -- a HIP kernel runs with f16 denormals on), with the two cases where the instruction's NaN
+ * handling differs from the definition below spelled out; tests/test_gpu_parity.py checks every half code and the
+ * neighbourhood of every rounding boundary against the host definition. */
 DM_HD uint16_t dm_f32_to_f16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (f != f) return (uint16_t)0x7e00u;
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+#else
     uint32_t u = dm_f2u(f);
     uint32_t sign = (u >> 16) & 0x8000u;
     uint32_t a = u & 0x7fffffffu;
@@ -257,8 +265,14 @@ DM_HD uint16_t dm_f32_to_f16(float f) {
     uint32_t rem = a & 0x1fffu;
     if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
     return (uint16_t)(sign | h);
+#endif
 }
 DM_HD float dm_f16_to_f32(uint16_t h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (((uint32_t)h & 0x7c00u) == 0x7c00u)   /* inf / NaN: payload carried over as below (the instruction would quiet a signalling NaN) */
+        return dm_u2f((((uint32_t)h & 0x8000u) << 16) | 0x7f800000u | (((uint32_t)h & 0x3ffu) << 13));
+    return (float)__builtin_bit_cast(_Float16, h);
+#else
     uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
     uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
     if (e == 0) {
@@ -268,6 +282,7 @@ DM_HD float dm_f16_to_f32(uint16_t h) {
     }
     if (e == 31) return dm_u2f(sign | 0x7f800000u | (m << 13));
     return dm_u2f(sign | ((e + 112u) << 23) | (m << 13));
+#endif
 }
 /* value of x after a round trip through binary16 (ti.cast(x, ti.f16) then back) */
 DM_HD float dm_round_f16(float x) { return dm_f16_to_f32(dm_f32_to_f16(x)); }

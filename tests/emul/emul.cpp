@@ -378,4 +378,8 @@ int emu_bsdf_selftest(int n, uint32_t seed) {
     }
     return bad;
 }
+// host definition of the two half conversions (include/vrt_detmath.h), for tests that pin numpy's against it
+void emu_half_probe(int op, int n, const uint32_t* in, uint32_t* out) {
+    for (int i = 0; i < n; i++) out[i] = op == 14 ? (uint32_t)dm_f32_to_f16(dm_u2f(in[i])) : dm_f2u(dm_f16_to_f32((uint16_t)(in[i] & 0xffffu)));
+}
 }

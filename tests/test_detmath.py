@@ -92,3 +92,20 @@ def test_random_stream():
     orc.lib().orc_unit_rng(C.c_uint32(1), C.c_uint32(2), C.c_uint32(3), C.c_uint32(0), 16, orc.fptr(c))
     assert np.array_equal(a, c) and not np.array_equal(a, b)
     assert np.array_equal(a, out[:16])
+
+
+def test_half_conversions_host_definition_equals_numpy_references():
+    """The numpy references of tests/test_gpu_parity.py::test_half_conversions_on_device_equal_host_definition are the
+    host definition of dm_f32_to_f16 / dm_f16_to_f32 (include/vrt_detmath.h, compiled into the emulation library)."""
+    import ctypes as C
+    import emu
+    from test_gpu_parity import half_conversion_cases
+    lib = emu.lib()
+    lib.emu_half_probe.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.emu_half_probe.restype = None
+    codes, ref32, words, ref16 = half_conversion_cases()
+    for op, inp, ref in ((15, codes, ref32), (14, words, ref16)):
+        inp = np.ascontiguousarray(inp, dtype=np.uint32)
+        out = np.empty_like(inp)
+        lib.emu_half_probe(op, inp.size, inp.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(out, ref), f"op {op}: {np.count_nonzero(out != ref)} differ, e.g. {hex(int(inp[out != ref][0]))}"

@@ -157,6 +157,50 @@ def test_detmath_on_device_equals_host():
         assert same.all(), f"op {op}: {np.count_nonzero(~same)} of {a.size} differ, e.g. a={a[~same][:3]} b={b[~same][:3]} gpu={out[~same][:3]} host={ref[~same][:3]}"
 
 
+def half_conversion_cases():
+    """Word sets and numpy references for the two binary16 conversions: every half code one way; the other way every
+    representable half, every midpoint between neighbouring halves and the floats next to those, overflow / underflow
+    edges, NaNs of either sign and payload, and a million random words."""
+    codes = np.arange(65536, dtype=np.uint32)
+    ref32 = codes.astype(np.uint16).view(np.float16).astype(np.float32).view(np.uint32)
+    e, m = (codes >> 10) & 31, codes & 1023  # the definition carries a NaN's payload over unchanged
+    ref32 = np.where(e == 31, ((codes & 0x8000) << 16) | 0x7f800000 | (m << 13), ref32).astype(np.uint32)
+    finite = ref32[(e != 31)]
+    halves = np.sort(finite.view(np.float32).astype(np.float64))
+    mids = ((halves[:-1] + halves[1:]) * 0.5).astype(np.float32).view(np.uint32)   # exactly representable in binary32
+    near = np.concatenate([finite, mids, mids + 1, mids - 1, finite + 1, finite - 1])
+    edges = np.array([0x477fefff, 0x477ff000, 0x477ff001, 0x47800000, 0x7f7fffff, 0x7f800000, 0xff800000, 0x33000000, 0x33000001,
+                      0x32ffffff, 0x00000001, 0x80000001, 0x007fffff, 0x7fc00000, 0xffc00000, 0x7f800001, 0xff800001, 0x7fffffff,
+                      0xffffffff, 0x7fa00000], dtype=np.uint32)
+    rng = np.random.default_rng(5)
+    words = np.concatenate([near.astype(np.uint32), edges, rng.integers(0, 1 << 32, 1 << 20, dtype=np.uint64).astype(np.uint32)])
+    f = words.view(np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        ref16 = f.astype(np.float16).view(np.uint16).astype(np.uint32)
+    ref16 = np.where(np.isnan(f), 0x7e00, ref16).astype(np.uint32)             # one canonical NaN code
+    return codes, ref32, words, ref16
+
+
+def test_half_conversions_on_device_equal_host_definition():
+    """dm_f32_to_f16 / dm_f16_to_f32 are hardware conversions on the device and bit manipulation on the host
+    (include/vrt_detmath.h).  tests/test_detmath.py pins the numpy references used here to the host definition."""
+    import ctypes as C
+    lib = _lib.load()
+
+    def probe(op, words):
+        a = np.ascontiguousarray(words, dtype=np.uint32).view(np.float32)
+        out = np.empty_like(a)
+        rc = lib.vrt_detmath_probe(0, op, a.size, a.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        return out.view(np.uint32)
+
+    codes, ref32, words, ref16 = half_conversion_cases()
+    got = probe(15, codes)
+    assert np.array_equal(got, ref32), f"{np.count_nonzero(got != ref32)} half codes convert differently"
+    got = probe(14, words)
+    assert np.array_equal(got, ref16), f"{np.count_nonzero(got != ref16)} floats convert differently, e.g. {hex(int(words[got != ref16][0]))}"
+
+
 def test_full_resolution_properties():
     """BASELINE config 2 size (1920x1080, 8 bounces): size-independent properties instead of the oracle."""
     mat, rgb, params = scenes.scene_s1(0)

@@ -592,6 +592,8 @@ __global__ void k_detmath_probe(int op, int n, const float* a, const float* b, f
         case 11: r = dm_sqrt(a[i]); break;
         case 12: r = a[i] * b[i] + a[i]; break;  // must NOT contract
         case 13: r = (float)dm_f2i(a[i]); break;
+        case 14: r = dm_u2f((uint32_t)dm_f32_to_f16(a[i])); break;             // the half code, as the low bits of the output word
+        case 15: r = dm_f16_to_f32((uint16_t)(dm_f2u(a[i]) & 0xffffu)); break;  // input word's low bits = half code
     }
     out[i] = r;
 }
