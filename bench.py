@@ -274,7 +274,7 @@ def main():
                          "path_samples_per_launch": int(samples_per_launch), "render_ms_per_launch": round(avg_ms, 4),
                          "temporal_ms_per_launch": round(st["temporal_ms"] / max(st["temporal_launches"], 1), 4),
                          "note": "HBM is the bound the tier names; the 128^3 working set is cache resident and the kernel is "
-                                 "VALU-issue bound (84 % of SIMD cycles, profiles/r01_v7_pmc_k_render_pool.txt). Launches overlap: "
+                                 "VALU-issue bound (profiles/r01_v9_pmc_k_render_pool.txt). Launches overlap: "
                                  "the duration is a launch's span, the step period is ms_per_step"},
         }
         if not args.no_cpu_baseline and world == 1:
