@@ -251,12 +251,15 @@ def main():
         samples_per_launch = st["path_samples"] / launches  # a launch renders own_px pixels x the fused samples
         achieved = bytes_per_sample * samples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
+        valu_insts = None
         # the render stage runs the pooled schedule (k_render_pool) unless VRT_RENDER=fused asks for the fused one
         render_kernel = "k_render" if os.environ.get("VRT_RENDER") == "fused" else "k_render_pool"
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile) and world == 1:  # measured on the one-GPU launch (whole frame); a tile's launch moves less
             try:
-                traffic = json.load(open(tfile)).get(f"{render_kernel}_bytes_per_launch")
+                tj = json.load(open(tfile))
+                traffic = tj.get(f"{render_kernel}_bytes_per_launch")
+                valu_insts = tj.get(f"{render_kernel}_valu_wave_insts_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -273,6 +276,10 @@ def main():
                          "queries_per_path_sample": round(q, 2), "closest_hits_per_path_sample": round(hc, 3),
                          "path_samples_per_launch": int(samples_per_launch), "render_ms_per_launch": round(avg_ms, 4),
                          "temporal_ms_per_launch": round(st["temporal_ms"] / max(st["temporal_launches"], 1), 4),
+                         # what actually bounds the kernel: wave-level VALU instructions per launch (PMC, profiles/traffic.json)
+                         # over the live launch duration, against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
+                         "valu_issue": ({"achieved": round(valu_insts / (avg_ms * 1e-3) / 1e9, 2), "peak": 614.4, "unit": "G wave-instructions/s",
+                                         "frac": round(valu_insts / (avg_ms * 1e-3) / 614.4e9, 4)} if (valu_insts and avg_ms > 0) else None),
                          "note": "HBM is the bound the tier names; the 128^3 working set is cache resident and the kernel is "
                                  "VALU-issue bound (profiles/r01_v9_pmc_k_render_pool.txt). Launches overlap: "
                                  "the duration is a launch's span, the step period is ms_per_step"},
