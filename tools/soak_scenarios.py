@@ -25,10 +25,11 @@ def second(cfg):
     import emu
     return emu.Emulated(cfg)
 
+SCALE = int(os.environ.get("SOAK_SCALE", "1"))   # frame sizes times this (bigger frames: more tiles, XCD bands, work ranges)
 bad = 0
 for k in range(n_cases):
     scene = ["s1", "sunlit", "dense", "s6"][int(rng.integers(0, 4))]
-    W, H = int(rng.integers(24, 120)), int(rng.integers(16, 90))
+    W, H = int(rng.integers(24, 120)) * SCALE, int(rng.integers(16, 90)) * SCALE
     depth, seed, restir = int(rng.integers(1, 7)), int(rng.integers(0, 1 << 30)), bool(rng.integers(0, 3) == 0)
     mat, rgb, params = scenes.SCENES[scene](int(rng.integers(0, 4)))
     sky = scene == "s6" and bool(rng.integers(0, 2))  # the physical sky with clouds, tables at 32 x 32 (precomputed by both sides)
