@@ -40,8 +40,17 @@ struct TemporalBuffers {
 };
 
 VRT_DEV f3 scrub(f3 c) {  // pathtracer.py:1069-1075
+#if defined(__HIP_DEVICE_COMPILE__)
+    // "NaN, infinite or negative" is one class test per component (v_cmp_class_f32: either NaN, either infinity, negative
+    // normal or subnormal; -0 is not < 0), without the branches the short-circuit form compiles to -- this runs on 32
+    // taps per pixel of the temporal pass
+    const int bad_classes = 0x001 | 0x002 | 0x004 | 0x008 | 0x010 | 0x200;  // sNaN qNaN -inf -normal -subnormal +inf
+    const bool bad = (bool)((int)__builtin_isfpclass(c.x, bad_classes) | (int)__builtin_isfpclass(c.y, bad_classes) |
+                            (int)__builtin_isfpclass(c.z, bad_classes));
+#else
     bool bad = dm_isnan(c.x) || dm_isinf(c.x) || c.x < 0.0f || dm_isnan(c.y) || dm_isinf(c.y) || c.y < 0.0f ||
                dm_isnan(c.z) || dm_isinf(c.z) || c.z < 0.0f;
+#endif
     return bad ? mk3(0.0f) : c;
 }
 VRT_DEV void render_res(const FrameParams& fp, int& rx, int& ry) {
