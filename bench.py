@@ -281,7 +281,7 @@ def main():
                          "valu_issue": ({"achieved": round(valu_insts / (avg_ms * 1e-3) / 1e9, 2), "peak": 614.4, "unit": "G wave-instructions/s",
                                          "frac": round(valu_insts / (avg_ms * 1e-3) / 614.4e9, 4)} if (valu_insts and avg_ms > 0) else None),
                          "note": "HBM is the bound the tier names; the 128^3 working set is cache resident and the kernel is "
-                                 "VALU-issue bound (profiles/r01_v9_pmc_k_render_pool.txt). Launches overlap: "
+                                 "VALU-issue bound (profiles/r01_v10_pmc_k_render_pool.txt). Launches overlap: "
                                  "the duration is a launch's span, the step period is ms_per_step"},
         }
         if not args.no_cpu_baseline and world == 1:
