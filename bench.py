@@ -198,6 +198,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # setup, not warm-up: the library allocates the buffers of its overlapped pipeline (second and third buffer set, the
+    # camera-ray tables of both render streams) on the first launches that use them; keep that out of a short --warmup
+    for _ in range(4):
+        step()
+    fence()
     for _ in range(args.warmup):
         step()
     fence()
@@ -220,7 +225,7 @@ def main():
                                 seed=SEED, device=local_rank)
         one = NativeSession(lib, "vrt_", cfg1)
         setup_session(one, mat, rgb, params)
-        for _ in range(args.warmup + args.steps):
+        for _ in range(step_no[0]):   # every step() so far: setup, warm-up and timed
             one.accumulate(SPP_PER_STEP)
         ref = one.fetch_hdr()
         one.close()
