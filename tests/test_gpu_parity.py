@@ -238,7 +238,7 @@ def test_sky_precompute_and_lookup_match_oracle():
     """Config-3 path at test size: transmittance LUT, cloud ambient, cloud accumulation, sky slices
     (atmos.py) on the GPU against the oracle, then a render that looks the tables up."""
     import os
-    cloud = np.load(os.path.join(os.path.dirname(_lib.SO_PATH), "data", "cloud_texture.npy"))
+    cloud = np.load(os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "data", "cloud_texture.npy"))
     mat, rgb, params = scenes.scene_s6(0)
     W, H, R = 160, 96, 64
     cfg = host.make_config(W, H, voxel_edges=0.0, exposure=2.0, max_depth=5, seed=5, sky_res=R)
@@ -265,7 +265,7 @@ def test_sky_precompute_and_lookup_match_oracle():
 @pytest.mark.parametrize("W,H", [(128, 80), (400, 136)])  # 8 and 25 tiles across: k_gris gives each XCD a band of 1 / 4 tile columns, the last bands short or empty
 def test_restir_with_sky_matches_oracle(W, H):
     import os
-    cloud = np.load(os.path.join(os.path.dirname(_lib.SO_PATH), "data", "cloud_texture.npy"))
+    cloud = np.load(os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "data", "cloud_texture.npy"))
     mat, rgb, params = scenes.scene_s6(0)
     R = 48
     cfg = host.make_config(W, H, voxel_edges=0.0, exposure=2.0, max_depth=6, seed=8, sky_res=R, use_restir=True)
