@@ -13,7 +13,7 @@
  * There is NO CPU backend: vrt_create fails if no gfx950 device is usable.
  *
  * Layouts: images are row-major [row v][column u], v = 0 at the bottom like the reference's
- * (u, v) field indices.  Voxel arrays are [x+64][y+64][z+64] (C order), the index space of
+ * (u, v) field indices.  Voxel arrays are [x+G/2][y+G/2][z+G/2] (C order; G = grid_res), the index space of
  * voxel_world.py:14-18.  Matrices are row-major 4x4 in mathematical convention (element
  * [row*4+col]); the facade has already transposed the glm-ordered arrays the reference receives
  * (pathtracer.py:266-268, 278-280) and supplies the inverses.
@@ -41,8 +41,10 @@ enum {
  * (atmos.py:66-67) made into parameters. */
 typedef struct vrt_config {
     int32_t width, height;        /* image_res */
-    int32_t grid_res;             /* voxel_grid_res, pathtracer.py:83 -- must be 128 */
-    float dx;                     /* voxel size in world units (scene.py:11: 1/64) */
+    int32_t grid_res;             /* voxel_grid_res: 128 (pathtracer.py:83) or 256 (BASELINE config 5; VoxelWorld and
+                                     VoxelOctreeRaytracer take it as a parameter: voxel_world.py:6, raytracer.py:7-9) */
+    float dx;                     /* voxel size in world units, must be 2 / grid_res: the grid spans the world box
+                                     [-1,1]^3 (scene.py:11: 1/64 at 128) */
     float voxel_edges;            /* voxel_world.py:25 */
     float exposure;               /* pathtracer.py:58 */
     int32_t max_depth;            /* MAX_RAY_DEPTH, 1..64 */
@@ -108,7 +110,7 @@ vrt_ctx* vrt_create(const vrt_config* cfg);
 void vrt_destroy(vrt_ctx* ctx);
 
 /* Renderer.set_voxel / get_voxel storage (pathtracer.py:1325-1334, voxel_world.py:7-18):
- * mat int8[128^3], rgb uint8[128^3][3]. */
+ * mat int8[G^3], rgb uint8[G^3][3] with G = grid_res, index [x+G/2][y+G/2][z+G/2]. */
 int vrt_upload_voxels(vrt_ctx* ctx, const int8_t* mat, const uint8_t* rgb);
 /* MaterialList (materials.py:48-112): 128 rows of 14 f32 in bsdf.py:26-37 field order. */
 int vrt_upload_materials(vrt_ctx* ctx, const float* table);

@@ -28,10 +28,11 @@ static M4 load_m4(const float* m) {
 extern "C" {
 
 orc_ctx* orc_create(const vrt_config* cfg, int n_threads) {
-    if (!cfg || cfg->grid_res != 128 || cfg->width <= 0 || cfg->height <= 0) return nullptr;
+    const int g = cfg ? cfg->grid_res : 0;
+    if (!cfg || g < 8 || g > 512 || (g & (g - 1)) != 0 || cfg->width <= 0 || cfg->height <= 0) return nullptr;
     orc_ctx* c = new orc_ctx();
     c->r.init(cfg->width, cfg->height, cfg->dx, cfg->voxel_edges, cfg->exposure, cfg->max_depth, cfg->use_restir != 0, cfg->seed,
-              cfg->sky_res > 0 ? cfg->sky_res : 64, n_threads);
+              cfg->sky_res > 0 ? cfg->sky_res : 64, n_threads, g);
     if (cfg->row_end > cfg->row_begin) {
         c->r.row_begin = cfg->row_begin;
         c->r.row_end = cfg->row_end;
@@ -41,7 +42,7 @@ orc_ctx* orc_create(const vrt_config* cfg, int n_threads) {
 void orc_destroy(orc_ctx* c) { delete c; }
 
 int orc_upload_voxels(orc_ctx* c, const int8_t* mat, const uint8_t* rgb) {
-    size_t n = (size_t)128 * 128 * 128;
+    size_t n = c->r.world.voxel_material.size();
     memcpy(c->r.world.voxel_material.data(), mat, n);
     memcpy(c->r.world.voxel_color.data(), rgb, n * 3);
     return 0;

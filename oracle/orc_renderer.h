@@ -77,12 +77,14 @@ struct Renderer {
     Stats stats;
 
     void init(int w, int h, float dx, float voxel_edges, float exposure_, int max_depth, bool restir, uint32_t seed_,
-              int sky_res, int threads) {
+              int sky_res, int threads, int grid_res = 128) {
         W = w; H = h; exposure = exposure_; max_ray_depth = max_depth; use_restir = restir; seed = seed_;
         n_threads = threads < 1 ? 1 : threads;
         row_begin = 0; row_end = h;
-        world.init(dx, 128, voxel_edges);
-        voxel_raytracer.init(128);
+        /* pathtracer.py:83-85 fixes voxel_grid_res = 128 at the call site; VoxelWorld and VoxelOctreeRaytracer are
+         * parametric in it (n_lods = log2(res), raytracer.py:9; offset -res//2, voxel_world.py:14) */
+        world.init(dx, grid_res, voxel_edges);
+        voxel_raytracer.init(grid_res);
         for (int i = 0; i < 128; i++) mat_list[i] = default_material();
         atmos.init(sky_res, seed_);
         size_t n = (size_t)w * h;

@@ -28,7 +28,7 @@ struct Stats { /* per-call counters for the algorithmic-bytes figure (SURVEY.md 
 struct VoxelOctreeRaytracer {
     int voxel_grid_res = 128;
     int n_lods = 7; /* raytracer.py:9 */
-    uint32_t lod_base[8];
+    uint32_t lod_base[16];
     std::vector<uint32_t> occupancy;
 
     void init(int res) {

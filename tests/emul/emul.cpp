@@ -23,7 +23,7 @@ struct Emu {
     vrt_scene_params scene;
     vrt_camera cam;
     std::vector<uint32_t> grid;
-    std::vector<unsigned long long> l0, l1, l2, l0c;
+    std::vector<unsigned long long> l0, l1, l2, l3, l0c;
     std::vector<uint32_t> l0c_base;  // [512] + count
     std::vector<float> mats, mats_x, sky_scat, sky_trans;
     std::vector<GrisGeo> gris_geo;
@@ -80,7 +80,9 @@ Emu* emu_create(const vrt_config* cfg) {
     c->buf0 = c->own0 - halo < 0 ? 0 : c->own0 - halo;
     c->buf1 = c->own1 + halo > cfg->height ? cfg->height : c->own1 + halo;
     size_t n = c->n = (size_t)(c->buf1 - c->buf0) * cfg->width;
-    c->grid.assign(128 * 128 * 128, 0); c->l0.assign(32768, 0); c->l1.assign(512, 0); c->l2.assign(8, 0);
+    if (cfg->grid_res != 128 && cfg->grid_res != 256) { delete c; return nullptr; }
+    const size_t nv = (size_t)cfg->grid_res * cfg->grid_res * cfg->grid_res;
+    c->grid.assign(nv, 0); c->l0.assign(nv / 64, 0); c->l1.assign(nv / 4096, 0); c->l2.assign(nv / 262144, 0); c->l3.assign(1, 0);
     c->mats.assign(128 * 14, 0.0f);
     f3 z = mk3(0.0f);
     c->cbuf[0].assign(n, z); c->cbuf[1].assign(n, z); c->color_s.assign(n, z); c->color_d2.assign(n, z); c->color_s2.assign(n, z);
@@ -99,17 +101,19 @@ Emu* emu_create(const vrt_config* cfg) {
 }
 void emu_destroy(Emu* c) { delete c; }
 int emu_upload_voxels(Emu* c, const int8_t* mat, const uint8_t* rgb) {
-    const int n = 128 * 128 * 128;
+    const int G = c->cfg.grid_res, n = G * G * G, n0 = G / 4;
     for (int i = 0; i < n; i++) {  // k_pack_grid
         int m = mat[i];
         uint32_t a = (m < 0) ? 0u : (uint32_t)m;
-        c->grid[i] = (uint32_t)rgb[3 * i] | ((uint32_t)rgb[3 * i + 1] << 8) | ((uint32_t)rgb[3 * i + 2] << 16) | (a << 24);
+        const int z = i % G, y = (i / G) % G, x = i / (G * G);
+        c->grid[G == 256 ? texel_index<256>(x, y, z) : texel_index<128>(x, y, z)] =
+            (uint32_t)rgb[3 * i] | ((uint32_t)rgb[3 * i + 1] << 8) | ((uint32_t)rgb[3 * i + 2] << 16) | (a << 24);
     }
-    for (int b = 0; b < 32768; b++) {  // k_build_l0
-        int bx = b & 31, by = (b >> 5) & 31, bz = b >> 10;
+    for (int b = 0; b < n0 * n0 * n0; b++) {  // k_build_l0
+        int bx = b % n0, by = (b / n0) % n0, bz = b / (n0 * n0);
         unsigned long long w = 0;
         for (int z = 0; z < 4; z++) for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++)
-            if (mat[((bx * 4 + x) * 128 + (by * 4 + y)) * 128 + (bz * 4 + z)] > 0) w |= 1ULL << (z * 16 + y * 4 + x);
+            if (mat[((size_t)(bx * 4 + x) * G + (by * 4 + y)) * G + (bz * 4 + z)] > 0) w |= 1ULL << (z * 16 + y * 4 + x);
         c->l0[b] = w;
     }
     auto coarse = [](const std::vector<unsigned long long>& fine, std::vector<unsigned long long>& out, int nc) {
@@ -122,11 +126,12 @@ int emu_upload_voxels(Emu* c, const int8_t* mat, const uint8_t* rgb) {
             out[b] = w;
         }
     };
-    coarse(c->l0, c->l1, 8);
-    coarse(c->l1, c->l2, 2);
-    // k_build_l0c: the fine level without its empty words
+    coarse(c->l0, c->l1, G / 16);
+    coarse(c->l1, c->l2, G / 64);
     c->l0c.assign(32768, 0ULL);
     c->l0c_base.assign(513, 0u);
+    if (G == 256) { coarse(c->l2, c->l3, 1); return 0; }
+    // k_build_l0c: the fine level without its empty words (128^3 only)
     uint32_t k = 0;
     for (int i = 0; i < 512; i++) {
         c->l0c_base[i] = k;
@@ -155,9 +160,9 @@ int emu_upload_sky(Emu* c, const float* scat, const float* trans) {
 
 }  // extern "C"
 
-template <bool RESTIR>
+template <int G, bool RESTIR>
 static void render_all(Emu* c, const FrameParams& fp, const SceneData& sc, const PixelBuffers& out) {
-    GlobalPyramid P;
+    GlobalPyramid<G> P;
     P.p = sc.pyr;
     for (int v = fp.row0; v < fp.row1; v++)
         for (int u = 0; u < fp.W; u++) {
@@ -173,8 +178,9 @@ static void render_all(Emu* c, const FrameParams& fp, const SceneData& sc, const
 // The pool kernel's stage functions (vrt_pool.h) stepped one path at a time: the record goes through the same
 // packed slot (here a 25-dword array) and scratch line as on the device, and every walk is suspended and
 // resumed every third step so that the packing of a half-done walk is exercised too.
+template <int G>
 static void render_all_pool(Emu* c, const FrameParams& fp, const SceneData& sc, const PixelBuffers& out) {
-    GlobalPyramid P;
+    GlobalPyramid<G> P;
     P.p = sc.pyr;
     // the launcher's choice of kernel variant (vrt_kernels.hip, launch_render_pool)
     const bool black_sun = !((fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f);
@@ -183,11 +189,11 @@ static void render_all_pool(Emu* c, const FrameParams& fp, const SceneData& sc, 
             if (outside_render_area(fp, (float)u, (float)v)) continue;
             uint32_t slot[PF_COUNT] = {0}, cold[PC_COUNT] = {0};
             SlotRef s{slot, 1};
-            int st = pool_begin(fp, s, u, v, 0, c->ts);
+            int st = pool_begin<G>(fp, s, u, v, 0, c->ts);
             while (st != SLOT_EMPTY) {
                 if (st == SLOT_RAY) {
                     RayWalk w;
-                    walk_load(s, w);
+                    walk_load<G>(s, w);
                     BrickCache bc{-1, 0ULL};
                     CoarseWords cw;
                     coarse_fetch(P, w.ix, w.iy, w.iz, cw);
@@ -197,11 +203,11 @@ static void render_all_pool(Emu* c, const FrameParams& fp, const SceneData& sc, 
                         const bool fin = walk_trip(P, w, bc, cw, nq);
                         c->ts.queries += (unsigned)nq;
                         if (fin) break;
-                        if (k % 3 == 0) { walk_store(s, w); walk_load(s, w); bc.key = -1; coarse_fetch(P, w.ix, w.iy, w.iz, cw); }
+                        if (k % 3 == 0) { walk_store(s, w); walk_load<G>(s, w); bc.key = -1; coarse_fetch(P, w.ix, w.iy, w.iz, cw); }
                     }
                     c->ts.iters += (unsigned)(w.iters - iters0);
                     walk_store(s, w);
-                    st = slot_state_after_walk(w.t, s.f(PF_FLOOR_T));
+                    st = slot_state_after_walk<G>(w.t, s.f(PF_FLOOR_T));
                 } else if (st == SLOT_SHADE) {
                     st = black_sun ? pool_shade<HIT_SOMETHING, true>(fp, sc, P, out, s, cold, c->ts)
                                    : pool_shade<HIT_SOMETHING, false>(fp, sc, P, out, s, cold, c->ts);
@@ -212,13 +218,12 @@ static void render_all_pool(Emu* c, const FrameParams& fp, const SceneData& sc, 
         }
 }
 
-extern "C" {
-
-int emu_accumulate(Emu* c, int n_samples) {
+template <int G>
+static int accumulate_g(Emu* c, int n_samples) {
     for (int s = 0; s < n_samples; s++) {
         FrameParams fp = frame_params(c);
         SceneData sc;
-        sc.pyr.l0 = c->l0.data(); sc.pyr.l1 = c->l1.data(); sc.pyr.l2 = c->l2.data();
+        sc.pyr.l0 = c->l0.data(); sc.pyr.l1 = c->l1.data(); sc.pyr.l2 = c->l2.data(); sc.pyr.l3 = c->l3.data();
         sc.pyr.l0c = c->l0c.data(); sc.pyr.l0c_base = c->l0c_base.data(); sc.pyr.l0c_count = c->l0c_base.data() + 512;
         sc.grid = c->grid.data(); sc.mats = c->mats.data();
         sc.sky.scattering = c->sky_scat.data(); sc.sky.transmittance = c->sky_trans.data();
@@ -239,7 +244,7 @@ int emu_accumulate(Emu* c, int n_samples) {
         const f3* cd = rt;
         const f3* cs = c->color_s.data();
         if (c->cfg.use_restir) {
-            render_all<true>(c, fp, sc, out);
+            render_all<G, true>(c, fp, sc, out);
             GrisBuffers gb;
             gb.color_d_in = rt; gb.color_s_in = c->color_s.data();
             gb.color_d_out = c->color_d2.data(); gb.color_s_out = c->color_s2.data();
@@ -250,7 +255,7 @@ int emu_accumulate(Emu* c, int n_samples) {
             gb.geo = c->gris_geo.data(); gb.src = c->gris_src.data(); gb.mats_x = c->mats_x.data();
             for (int v = fp.row0; v < fp.row1; v++)
                 for (int u = 0; u < fp.W; u++) gris_prepare_pixel(fp, sc, gb, u, v);
-            GlobalPyramid P;
+            GlobalPyramid<G> P;
             P.p = sc.pyr;
             int g0 = c->own0 - 2 < c->buf0 ? c->buf0 : c->own0 - 2, g1 = c->own1 + 2 > c->buf1 ? c->buf1 : c->own1 + 2;
             for (int v = g0; v < g1; v++)
@@ -265,9 +270,9 @@ int emu_accumulate(Emu* c, int n_samples) {
             cd = c->color_d2.data();
             cs = c->color_s2.data();
         } else if (getenv("VRT_EMU_POOL")) {
-            render_all_pool(c, fp, sc, out);
+            render_all_pool<G>(c, fp, sc, out);
         } else {
-            render_all<false>(c, fp, sc, out);
+            render_all<G, false>(c, fp, sc, out);
         }
         TemporalBuffers tb;
         tb.color_d = cd; tb.color_s = cs;
@@ -288,6 +293,10 @@ int emu_accumulate(Emu* c, int n_samples) {
     }
     return 0;
 }
+
+extern "C" {
+
+int emu_accumulate(Emu* c, int n_samples) { return c->cfg.grid_res == 256 ? accumulate_g<256>(c, n_samples) : accumulate_g<128>(c, n_samples); }
 int emu_reset(Emu* c) {
     for (int s = 0; s < 2; s++) {
         std::fill(c->hist_d[s].begin(), c->hist_d[s].end(), mk4(0, 0, 0, 0));

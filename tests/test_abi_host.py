@@ -40,7 +40,8 @@ def test_no_cpu_fallback():
 
 def test_create_rejects_bad_config():
     lib = _lib.load()
-    for field, value in (("grid_res", 64), ("width", 0), ("max_depth", 0), ("sky_res", 7)):
+    # grid_res is 128 or 256 and the voxel size follows from it (dx = 2 / grid_res: include/vrt_api.h)
+    for field, value in (("grid_res", 64), ("grid_res", 256), ("dx", 1.0 / 128.0), ("width", 0), ("max_depth", 0), ("sky_res", 7)):
         cfg = host.make_config(64, 64)
         setattr(cfg, field, value)
         assert lib.vrt_create(C.byref(cfg)) is None
@@ -80,9 +81,12 @@ def test_material_table():
 
 def test_scenes_are_deterministic_and_shaped():
     for name, fn in scenes.SCENES.items():
+        if name in ("sponge256", "dense256"):
+            continue  # 256^3 builders take seconds each: tests/test_grid256.py renders them
         m1, c1, p1 = fn(0) if name != "dense" else fn(12345)
         m2, c2, _ = fn(0) if name != "dense" else fn(12345)
-        assert m1.shape == (128, 128, 128) and m1.dtype == np.int8 and c1.shape == (128, 128, 128, 3) and c1.dtype == np.uint8
+        g = 256 if name.endswith("256") else 128
+        assert m1.shape == (g, g, g) and m1.dtype == np.int8 and c1.shape == (g, g, g, 3) and c1.dtype == np.uint8
         assert np.array_equal(m1, m2) and np.array_equal(c1, c2)
         assert (m1 > 0).any() and not c1[m1 == 0].any()
     m, _, _ = scenes.scene_dense(12345)

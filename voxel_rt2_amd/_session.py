@@ -56,8 +56,9 @@ class NativeSession:
     def upload_voxels(self, mat, rgb):
         mat = np.ascontiguousarray(mat, dtype=np.int8)
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
-        if mat.shape != (128, 128, 128) or rgb.shape != (128, 128, 128, 3):
-            raise ValueError("voxel arrays must be int8[128,128,128] and uint8[128,128,128,3]")
+        g = int(self.cfg.grid_res)
+        if mat.shape != (g, g, g) or rgb.shape != (g, g, g, 3):
+            raise ValueError(f"voxel arrays must be int8[{g},{g},{g}] and uint8[{g},{g},{g},3] (grid_res = {g})")
         self._call("upload_voxels", mat.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p))
 
     def upload_materials(self, table):

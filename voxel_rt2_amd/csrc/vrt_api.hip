@@ -49,7 +49,7 @@ struct vrt_ctx {
     size_t npix = 0;          // (buf1 - buf0) * W
     // scene data
     int8_t* d_mat = nullptr; uint8_t* d_rgb = nullptr; uint32_t* d_grid = nullptr;
-    unsigned long long *d_l0 = nullptr, *d_l1 = nullptr, *d_l2 = nullptr, *d_l0c = nullptr;
+    unsigned long long *d_l0 = nullptr, *d_l1 = nullptr, *d_l2 = nullptr, *d_l3 = nullptr, *d_l0c = nullptr;
     uint32_t* d_l0c_base = nullptr;  // [512] offsets + [1] count
     float* d_mats = nullptr;
     Counters* d_counters = nullptr;
@@ -164,7 +164,7 @@ static FrameParams make_frame_params(const vrt_ctx* c) {
 }
 static SceneData make_scene_data(const vrt_ctx* c) {
     SceneData sc;
-    sc.pyr.l0 = c->d_l0; sc.pyr.l1 = c->d_l1; sc.pyr.l2 = c->d_l2;
+    sc.pyr.l0 = c->d_l0; sc.pyr.l1 = c->d_l1; sc.pyr.l2 = c->d_l2; sc.pyr.l3 = c->d_l3;
     sc.pyr.l0c = c->d_l0c; sc.pyr.l0c_base = c->d_l0c_base; sc.pyr.l0c_count = c->d_l0c_base + 512;
     sc.grid = c->d_grid;
     sc.mats = c->d_mats;
@@ -197,11 +197,11 @@ const char* vrt_last_error(void) { return g_err.c_str(); }
 
 vrt_ctx* vrt_create(const vrt_config* cfg) {
     if (!cfg) { fail(VRT_E_INVALID, "null config"); return nullptr; }
-    if (cfg->grid_res != 128) { fail(VRT_E_INVALID, "grid_res must be 128 (pathtracer.py:83)"); return nullptr; }
+    if (cfg->grid_res != 128 && cfg->grid_res != 256) { fail(VRT_E_INVALID, "grid_res must be 128 (pathtracer.py:83) or 256"); return nullptr; }
     if (cfg->width <= 0 || cfg->height <= 0 || cfg->width > 16384 || cfg->height > 16384) { fail(VRT_E_INVALID, "bad image size"); return nullptr; }
     if (cfg->max_depth < 1 || cfg->max_depth > 64) { fail(VRT_E_INVALID, "max_depth must be in 1..64"); return nullptr; }
     if (cfg->sky_res < 0 || cfg->sky_res > 8192 || (cfg->sky_res > 0 && cfg->sky_res < 32)) { fail(VRT_E_INVALID, "sky_res must be 0 or 32..8192"); return nullptr; }
-    if (cfg->dx != 1.0f / 64.0f) { fail(VRT_E_INVALID, "dx must be 1/64 (scene.py:11)"); return nullptr; }
+    if (cfg->dx != 2.0f / (float)cfg->grid_res) { fail(VRT_E_INVALID, "dx must be 2 / grid_res: 1/64 at 128 (scene.py:11), 1/128 at 256 -- the grid spans the world box [-1, 1]^3"); return nullptr; }
     int own0 = 0, own1 = cfg->height;
     if (cfg->row_end > cfg->row_begin) {
         if (cfg->row_begin < 0 || cfg->row_end > cfg->height) { fail(VRT_E_INVALID, "row range outside the image"); return nullptr; }
@@ -229,10 +229,11 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
     c->buf1 = own1 + c->halo > cfg->height ? cfg->height : own1 + c->halo;
     c->npix = (size_t)(c->buf1 - c->buf0) * cfg->width;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    const size_t nvox = (size_t)128 * 128 * 128, n = c->npix;
+    const size_t G = (size_t)cfg->grid_res, nvox = G * G * G, n = c->npix;
+    const size_t nw0 = nvox / 64, nw1 = nw0 / 64, nw2 = nw1 / 64;  // words of the brick levels
     ok = ok && dalloc(&c->d_mat, nvox) == hipSuccess && dalloc(&c->d_rgb, nvox * 3) == hipSuccess && dalloc(&c->d_grid, nvox) == hipSuccess;
-    ok = ok && dalloc(&c->d_l0, 32768) == hipSuccess && dalloc(&c->d_l1, 512) == hipSuccess && dalloc(&c->d_l2, 8) == hipSuccess &&
-         dalloc(&c->d_l0c, 32768) == hipSuccess && dalloc(&c->d_l0c_base, 513) == hipSuccess;
+    ok = ok && dalloc(&c->d_l0, nw0) == hipSuccess && dalloc(&c->d_l1, nw1) == hipSuccess && dalloc(&c->d_l2, nw2) == hipSuccess &&
+         dalloc(&c->d_l3, 1) == hipSuccess && dalloc(&c->d_l0c, 32768) == hipSuccess && dalloc(&c->d_l0c_base, 513) == hipSuccess;
     ok = ok && dalloc(&c->d_mats, 128 * 14) == hipSuccess && dalloc(&c->d_counters, 1) == hipSuccess && dalloc(&c->d_work, 4 * VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE) == hipSuccess;
     ok = ok && dalloc(&c->d_cbuf[0], n) == hipSuccess && dalloc(&c->d_cbuf[1], n) == hipSuccess && dalloc(&c->d_spec_planes, n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->d_gb_pos, n) == hipSuccess;
     ok = ok && dalloc(&c->d_gb_mat, n) == hipSuccess && dalloc(&c->d_refl_planes, n * VRT_MAX_FUSED) == hipSuccess;
@@ -288,7 +289,7 @@ void vrt_destroy(vrt_ctx* c) {
     void* ptrs[] = {c->d_prim_cache[0], c->d_prim_cache[1], c->alt_multi_d[0], c->alt_spec_planes[0], c->alt_refl_planes[0], c->alt_gb_pos[0], c->alt_gb_mat[0],
                     c->alt_multi_d[1], c->alt_spec_planes[1], c->alt_refl_planes[1], c->alt_gb_pos[1], c->alt_gb_mat[1],
                     c->alt_pool_scratch, c->d_gb_normal[2], c->d_gb_depth[2], c->d_gb_normal[3], c->d_gb_depth[3],
-                    c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l0c, c->d_l0c_base, c->d_mats, c->d_counters, c->d_work, c->d_sky_scat,
+                    c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l3, c->d_l0c, c->d_l0c_base, c->d_mats, c->d_counters, c->d_work, c->d_sky_scat,
                     c->d_sky_trans, c->d_cloud_ambient, c->d_trans_lut, c->d_cloud_tex, c->d_cbuf[0], c->d_cbuf[1], c->d_spec_planes, c->d_color_d2,
                     c->d_color_s2, c->d_gb_pos, c->d_gb_normal[0], c->d_gb_normal[1], c->d_gb_depth[0], c->d_gb_depth[1],
                     c->d_gb_mat, c->d_refl_planes, c->d_gb_refl_f, c->d_hist_d[0], c->d_hist_d[1], c->d_hist_s[0], c->d_hist_s[1],
@@ -302,7 +303,7 @@ void vrt_destroy(vrt_ctx* c) {
 int vrt_upload_voxels(vrt_ctx* c, const int8_t* mat, const uint8_t* rgb) {
     if (!c || !mat || !rgb) return fail(VRT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    const size_t nvox = (size_t)128 * 128 * 128;
+    const size_t nvox = (size_t)c->cfg.grid_res * c->cfg.grid_res * c->cfg.grid_res;
     HIP_TRY(hipMemcpyAsync(c->d_mat, mat, nvox, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_rgb, rgb, nvox * 3, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));  // host buffers are only borrowed for the call
@@ -352,7 +353,7 @@ int vrt_prepare(vrt_ctx* c) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     c->main_dirty = true;
-    HIP_TRY(launch_prepare(c->stream, c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l0c, c->d_l0c_base));
+    HIP_TRY(launch_prepare(c->stream, c->cfg.grid_res, c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l3, c->d_l0c, c->d_l0c_base));
     if (c->scene.use_physical_sky == 1) {
         SkyPrecompute sp = make_sky(c);
         f3 sd, sc_;
@@ -409,7 +410,7 @@ static bool ensure_overlap(vrt_ctx* c) {
         ok = dalloc(&c->alt_multi_d[s], n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->alt_spec_planes[s], n * VRT_MAX_FUSED) == hipSuccess &&
              dalloc(&c->alt_refl_planes[s], n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->alt_gb_pos[s], n) == hipSuccess &&
              dalloc(&c->alt_gb_mat[s], n) == hipSuccess && hipStreamCreateWithFlags(&c->rstream[s], hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->alt_pool_scratch, pool_scratch_bytes(c->render_blocks)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->alt_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->render_blocks)) == hipSuccess;
     for (int s = 0; s < 3 && ok; s++)
         ok = hipEventCreateWithFlags(&c->ev_r[s], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_t[s], hipEventDisableTiming) == hipSuccess;
@@ -445,8 +446,8 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
             else if (strcmp(e, "pool") != 0) return fail(VRT_E_INVALID, "VRT_RENDER must be 'fused' or 'pool'");
         }
         int per_cu = 0;
-        if (pooled) HIP_TRY(query_render_pool_residency(instr, &per_cu));
-        else HIP_TRY(query_render_residency(restir, instr, &per_cu));
+        if (pooled) HIP_TRY(query_render_pool_residency(c->cfg.grid_res, instr, &per_cu));
+        else HIP_TRY(query_render_residency(c->cfg.grid_res, restir, instr, &per_cu));
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
         c->render_blocks = per_cu * c->n_cu;
@@ -454,10 +455,10 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         if (pooled) {
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (c->d_pool_scratch) { HIP_TRY(hipFree(c->d_pool_scratch)); c->d_pool_scratch = nullptr; }
-            HIP_TRY(hipMalloc((void**)&c->d_pool_scratch, pool_scratch_bytes(c->render_blocks)));
+            HIP_TRY(hipMalloc((void**)&c->d_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->render_blocks)));
             if (c->alt_pool_scratch) {
                 HIP_TRY(hipFree(c->alt_pool_scratch)); c->alt_pool_scratch = nullptr;
-                HIP_TRY(hipMalloc((void**)&c->alt_pool_scratch, pool_scratch_bytes(c->render_blocks)));
+                HIP_TRY(hipMalloc((void**)&c->alt_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->render_blocks)));
             }
         }
     }
@@ -542,8 +543,8 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
             if (!c->d_prim_cache[which] && dalloc(&c->d_prim_cache[which], c->npix) != hipSuccess) { (void)hipGetLastError(); c->d_prim_cache[which] = nullptr; }
             prim = c->d_prim_cache[which];
         }
-        if (c->pooled) HIP_TRY(launch_render_pool(rs, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch : c->d_pool_scratch, c->drain_signal, prim));
-        else HIP_TRY(launch_render(rs, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g));
+        if (c->pooled) HIP_TRY(launch_render_pool(rs, c->cfg.grid_res, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch : c->d_pool_scratch, c->drain_signal, prim));
+        else HIP_TRY(launch_render(rs, c->cfg.grid_res, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g));
         c->drain_signalled = c->pooled && c->drain_signal != nullptr;
         HIP_TRY(hipEventRecord(b, rs));
         if (overlapped) {
@@ -561,7 +562,7 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
             int g0 = c->own0 - 2 < c->buf0 ? c->buf0 : c->own0 - 2, g1 = c->own1 + 2 > c->buf1 ? c->buf1 : c->own1 + 2;
             if (record(c, 2, &a, &b) != VRT_OK) return VRT_E_DEVICE;
             HIP_TRY(hipEventRecord(a, c->stream));
-            HIP_TRY(launch_gris(c->stream, instr, fp, sc, gb, g0, g1));
+            HIP_TRY(launch_gris(c->stream, c->cfg.grid_res, instr, fp, sc, gb, g0, g1));
             HIP_TRY(hipEventRecord(b, c->stream));
             cd = c->d_color_d2;
             cs = c->d_color_s2;

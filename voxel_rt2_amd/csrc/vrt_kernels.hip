@@ -29,24 +29,27 @@ namespace vrt {
 
 // ---- prepare_data ----------------------------------------------------------------------------
 // voxel_world.py:69-87: rgba8 texel per voxel; a negative material byte stores 0 (unorm clamp)
-__global__ void k_pack_grid(const int8_t* __restrict__ mat, const uint8_t* __restrict__ rgb, uint32_t* __restrict__ grid, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+template <int G>
+__global__ void k_pack_grid(const int8_t* __restrict__ mat, const uint8_t* __restrict__ rgb, uint32_t* __restrict__ grid) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;  // [x][y][z], the order of the uploaded arrays
+    if (i >= G * G * G) return;
     int m = mat[i];
     uint32_t a = (m < 0) ? 0u : (uint32_t)m;
-    grid[i] = (uint32_t)rgb[3 * i] | ((uint32_t)rgb[3 * i + 1] << 8) | ((uint32_t)rgb[3 * i + 2] << 16) | (a << 24);
+    const int z = i & (G - 1), y = (i / G) & (G - 1), x = i / (G * G);
+    grid[texel_index<G>(x, y, z)] = (uint32_t)rgb[3 * i] | ((uint32_t)rgb[3 * i + 1] << 8) | ((uint32_t)rgb[3 * i + 2] << 16) | (a << 24);
 }
 // raytracer.py:46-53: LOD-0 bit = voxel_material > 0 (signed), gathered into one 4x4x4 brick word per thread
-__global__ void k_build_l0(const int8_t* __restrict__ mat, unsigned long long* __restrict__ l0) {
+__global__ void k_build_l0(const int8_t* __restrict__ mat, unsigned long long* __restrict__ l0, int G) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= 32 * 32 * 32) return;
-    int bx = b & 31, by = (b >> 5) & 31, bz = b >> 10;
+    const int n0 = G >> 2;
+    if (b >= n0 * n0 * n0) return;
+    int bx = b % n0, by = (b / n0) % n0, bz = b / (n0 * n0);
     unsigned long long w = 0ULL;
     for (int z = 0; z < 4; z++)
         for (int y = 0; y < 4; y++)
             for (int x = 0; x < 4; x++) {
                 int vx = bx * 4 + x, vy = by * 4 + y, vz = bz * 4 + z;
-                if (mat[(vx * VRT_GRID + vy) * VRT_GRID + vz] > 0) w |= 1ULL << (z * 16 + y * 4 + x);
+                if (mat[(vx * G + vy) * G + vz] > 0) w |= 1ULL << (z * 16 + y * 4 + x);
             }
     l0[b] = w;
 }
@@ -97,19 +100,25 @@ __global__ void k_build_l0c(const unsigned long long* __restrict__ l0, const uns
 }
 
 // ---- render ----------------------------------------------------------------------------------
+template <int G_>
 struct LdsPyramid {  // coarse levels in LDS, fine level through L2
+    static constexpr int G = G_;
     static constexpr bool flat_descend = false;  // its kernels walk with few active lanes: descend()'s early outs win
     const unsigned long long* l0;
     const unsigned long long* l1;
     const unsigned long long* l2;
+    unsigned long long w3;   // the top word (G = 256), wave-uniform
     __device__ __forceinline__ unsigned long long load_l0(int i) const { return l0[i]; }
     __device__ __forceinline__ unsigned long long load_l1(int i) const { return l1[i]; }
     __device__ __forceinline__ unsigned long long load_l2(int i) const { return l2[i]; }
+    __device__ __forceinline__ unsigned long long load_l3() const { return w3; }
 };
-// The pooled kernel's view: each l1 word beside its parent l2 word ({w1, w2}[512], one 16-byte LDS read per cell),
-// and the head of the compacted fine level (Pyramid::l0c) in LDS too -- a sparse scene's fine level is a few
+// The pooled kernel's view.  128^3: each l1 word beside its parent l2 word ({w1, w2}[512], one 16-byte LDS read per
+// cell), and the head of the compacted fine level (Pyramid::l0c) in LDS too -- a sparse scene's fine level is a few
 // hundred words, and the fine word is the load every other DDA step depends on (L2: ~700 cycles, LDS: ~130).
+template <int G_>
 struct LdsPyramid2 {
+    static constexpr int G = G_;
     static constexpr bool flat_descend = true;   // the pooled kernel walks with nearly full waves
     const unsigned long long* l0;
     const ulonglong2* l12;
@@ -120,13 +129,40 @@ struct LdsPyramid2 {
     __device__ __forceinline__ unsigned long long load_l0(int i) const { return l0[i]; }
     __device__ __forceinline__ unsigned long long load_l1(int i) const { return l12[i].x; }
     __device__ __forceinline__ unsigned long long load_l2(int i) const { return l2[i]; }
+    __device__ __forceinline__ unsigned long long load_l3() const { return 0ULL; }
     __device__ __forceinline__ unsigned long long load_fine(int key, uint32_t idx) const { return idx < n_fine ? fine[idx] : l0[key]; }
-    __device__ __forceinline__ void load_coarse(int i1, unsigned long long& w1, unsigned long long& w2, uint32_t& base) const {
+    __device__ __forceinline__ void load_coarse(int i1, int i2, unsigned long long& w1, unsigned long long& w2, uint32_t& base) const {
+        (void)i2;
         const ulonglong2 v = l12[i1];
         w1 = v.x; w2 = v.y;
         base = fine_base[i1];
     }
 };
+// 256^3: the whole l1 level (16^3 words, 32 KiB) and l2 (4^3 words) resident in LDS -- the brick cache of this grid:
+// every coarse query of every DDA step is an LDS read -- the top word in scalar registers, and the fine words (2 MiB:
+// they miss LDS by a factor of 13) through L1 / L2 with the current brick's word cached in registers per ray.  A
+// workgroup is eight waves (one per CU: eight 13.5 KB path pools + 32.5 KB of pyramid + the material table = 148 KB of
+// the CU's 160 KB), so the level is staged once per CU.
+template <>
+struct LdsPyramid2<256> {
+    static constexpr int G = 256;
+    static constexpr bool flat_descend = true;
+    const unsigned long long* l0;
+    const unsigned long long* l1;   // LDS [4096]
+    const unsigned long long* l2;   // LDS [64]
+    unsigned long long w3;
+    __device__ __forceinline__ unsigned long long load_l0(int i) const { return l0[i]; }
+    __device__ __forceinline__ unsigned long long load_l1(int i) const { return l1[i]; }
+    __device__ __forceinline__ unsigned long long load_l2(int i) const { return l2[i]; }
+    __device__ __forceinline__ unsigned long long load_l3() const { return w3; }
+    __device__ __forceinline__ unsigned long long load_fine(int key, uint32_t idx) const { (void)idx; return l0[key]; }
+    __device__ __forceinline__ void load_coarse(int i1, int i2, unsigned long long& w1, unsigned long long& w2, uint32_t& base) const {
+        w1 = l1[i1]; w2 = l2[i2];
+        base = 0u;
+    }
+};
+template <int G> struct PoolGeom { static constexpr int waves = VRT_POOL_WAVES; };   // waves (= path pools) per workgroup
+template <> struct PoolGeom<256> { static constexpr int waves = 8; };
 
 __device__ __forceinline__ void flush_stats(const TraceStats& ts, Counters* c) {
     // wave-level sum, one atomic per counter per wave
@@ -140,19 +176,21 @@ __device__ __forceinline__ void flush_stats(const TraceStats& ts, Counters* c) {
     }
 }
 
-template <bool RESTIR, bool INSTR>
+template <int G, bool RESTIR, bool INSTR>
 __global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_render(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, unsigned chunk, int n_samples) {
-    __shared__ unsigned long long s_l1[512];
-    __shared__ unsigned long long s_l2[8];
+    constexpr int N1 = GridDim<G>::n1 * GridDim<G>::n1 * GridDim<G>::n1, N2 = GridDim<G>::n2 * GridDim<G>::n2 * GridDim<G>::n2;
+    __shared__ unsigned long long s_l1[N1];
+    __shared__ unsigned long long s_l2[N2];
     __shared__ float s_mats[128 * 14];
-    for (int i = threadIdx.x; i < 512; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
-    if (threadIdx.x < 8) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
+    for (int i = threadIdx.x; i < N1; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
+    if (threadIdx.x < N2) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
     for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
     if (blockIdx.x == 0 && threadIdx.x < VRT_WORK_HEADS) next_counter[threadIdx.x * VRT_WORK_HEAD_STRIDE] = 0u;  // the next launch's heads (idle during this launch)
     if (blockIdx.x == 0 && threadIdx.x == 0) next_counter[1] = 0u;  // and its "drain announced" word
     __syncthreads();
-    LdsPyramid P;
+    LdsPyramid<G> P;
     P.l0 = sc.pyr.l0; P.l1 = s_l1; P.l2 = s_l2;
+    P.w3 = (G == 256) ? sc.pyr.l3[0] : 0ULL;
     SceneData scl = sc;
     scl.mats = s_mats;
 
@@ -243,32 +281,45 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-template <bool INSTR, bool BLACK_SUN>
+template <int G, bool INSTR, bool BLACK_SUN>
 // 208 registers per wave (the attribute counts half of the unified file): two waves per SIMD then leave the 96 that
 // k_temporal runs in beside them (see there).  The allocator would take 238; the cap costs 28 bytes of scratch.
 #ifndef VRT_POOL_HALF_VGPRS
 #define VRT_POOL_HALF_VGPRS 104
 #endif
-__global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(VRT_POOL_HALF_VGPRS))) void k_render_pool(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
-    __shared__ ulonglong2 s_l12[512];
-    __shared__ unsigned long long s_l2[8];
-    __shared__ unsigned long long s_fine[VRT_POOL_FINE_WORDS];
-    __shared__ uint32_t s_fine_base[512];
+__global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(VRT_POOL_HALF_VGPRS))) void k_render_pool(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
+    constexpr int WAVES = PoolGeom<G>::waves;
+    constexpr bool BIG = (G == 256);   // which coarse levels are staged how: see LdsPyramid2
+    __shared__ ulonglong2 s_l12[BIG ? 1 : 512];
+    __shared__ unsigned long long s_l1[BIG ? 4096 : 1];
+    __shared__ unsigned long long s_l2[BIG ? 64 : 8];
+    __shared__ unsigned long long s_fine[BIG ? 1 : VRT_POOL_FINE_WORDS];
+    __shared__ uint32_t s_fine_base[BIG ? 1 : 512];
     __shared__ float s_mats[128 * 14];
-    __shared__ uint32_t s_pool[VRT_POOL_WAVES][PF_COUNT * VRT_POOL_SLOTS];
-    __shared__ uint32_t s_state[VRT_POOL_WAVES][VRT_POOL_WORDS * 64];
-    __shared__ uint32_t s_list[VRT_POOL_WAVES][VRT_POOL_SLOTS];
-    for (int i = threadIdx.x; i < 512; i += blockDim.x) {
-        ulonglong2 v;
-        v.x = sc.pyr.l1[i];
-        v.y = sc.pyr.l2[(((i >> 8) & 1) << 2) | (((i >> 5) & 1) << 1) | ((i >> 2) & 1)];
-        s_l12[i] = v;
-        s_fine_base[i] = sc.pyr.l0c_base[i];
+    __shared__ uint32_t s_pool[WAVES][PF_COUNT * VRT_POOL_SLOTS];
+    __shared__ uint32_t s_state[WAVES][VRT_POOL_WORDS * 64];
+    __shared__ uint32_t s_list[WAVES][VRT_POOL_SLOTS];
+    LdsPyramid2<G> P;
+    P.l0 = sc.pyr.l0; P.l2 = s_l2;
+    if constexpr (BIG) {
+        for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
+        if (threadIdx.x < 64) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
+        P.l1 = s_l1;
+        P.w3 = sc.pyr.l3[0];
+    } else {
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) {
+            ulonglong2 v;
+            v.x = sc.pyr.l1[i];
+            v.y = sc.pyr.l2[(((i >> 8) & 1) << 2) | (((i >> 5) & 1) << 1) | ((i >> 2) & 1)];
+            s_l12[i] = v;
+            s_fine_base[i] = sc.pyr.l0c_base[i];
+        }
+        if (threadIdx.x < 8) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
+        uint32_t n_fine = *sc.pyr.l0c_count;  // non-empty fine words of the scene; the first VRT_POOL_FINE_WORDS live in LDS
+        if (n_fine > VRT_POOL_FINE_WORDS) n_fine = VRT_POOL_FINE_WORDS;
+        for (uint32_t i = threadIdx.x; i < n_fine; i += blockDim.x) s_fine[i] = sc.pyr.l0c[i];
+        P.l12 = s_l12; P.fine_base = s_fine_base; P.fine = s_fine; P.n_fine = n_fine;
     }
-    if (threadIdx.x < 8) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
-    uint32_t n_fine = *sc.pyr.l0c_count;  // non-empty fine words of the scene; the first VRT_POOL_FINE_WORDS live in LDS
-    if (n_fine > VRT_POOL_FINE_WORDS) n_fine = VRT_POOL_FINE_WORDS;
-    for (uint32_t i = threadIdx.x; i < n_fine; i += blockDim.x) s_fine[i] = sc.pyr.l0c[i];
     for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
     if (blockIdx.x == 0 && threadIdx.x < VRT_WORK_HEADS) next_counter[threadIdx.x * VRT_WORK_HEAD_STRIDE] = 0u;  // the next launch's heads (idle during this launch)
     if (blockIdx.x == 0 && threadIdx.x == 0) next_counter[1] = 0u;  // and its "drain announced" word
@@ -278,12 +329,9 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) __attribut
     uint32_t* const list = s_list[wave];
     for (int k = 0; k < VRT_POOL_WORDS; k++) state[k * 64 + lane] = (k * 64 + lane < VRT_POOL_SLOTS) ? (uint32_t)SLOT_EMPTY : 4u;
     __syncthreads();
-    LdsPyramid2 P;
-    P.l0 = sc.pyr.l0; P.l12 = s_l12; P.l2 = s_l2;
-    P.fine_base = s_fine_base; P.fine = s_fine; P.n_fine = n_fine;
     SceneData scl = sc;
     scl.mats = s_mats;
-    uint32_t* const cold_wave = cold + (size_t)(blockIdx.x * VRT_POOL_WAVES + wave) * VRT_POOL_SLOTS * PC_COUNT;
+    uint32_t* const cold_wave = cold + (size_t)(blockIdx.x * WAVES + wave) * VRT_POOL_SLOTS * PC_COUNT;
 
     const int tiles_x = (fp.W + 7) >> 3;
     const int tiles_y = (fp.row1 - fp.row0 + 7) >> 3;
@@ -368,7 +416,7 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) __attribut
                 if (ended) {
                     VRT_REGION(16);
                     walk_store(s, w);
-                    state[slot] = (uint32_t)slot_state_after_walk(w.t, s.f(PF_FLOOR_T));
+                    state[slot] = (uint32_t)slot_state_after_walk<G>(w.t, s.f(PF_FLOOR_T));
                     if (!INSTR && prim_cache) {  // the camera ray of a pixel's sample 0: leave its record for the other samples
                         const uint32_t ids = s.u(PF_IDS);
                         if ((ids >> 24) == 0u) {  // depth 0, sample 0
@@ -396,7 +444,7 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) __attribut
                         VRT_REGION(15);
                         slot = (int)list[idx];
                         s.base = pool + slot;
-                        walk_load(s, w);
+                        walk_load<G>(s, w);
                         coarse_fetch(P, w.ix, w.iy, w.iz, cw);
                         bc.key = -1;
                         iters0 = w.iters;
@@ -473,7 +521,7 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) __attribut
                                 rec.x = r4.x; rec.y = r4.y; rec.z = r4.z; rec.w = r4.w;
                                 known = rec.w == prim_tag;
                             }
-                            state[slot] = (uint32_t)(known ? pool_begin_known(fp, s, u, v, sample, rec) : pool_begin(fp, s, u, v, sample, ts));
+                            state[slot] = (uint32_t)(known ? pool_begin_known<G>(fp, s, u, v, sample, rec) : pool_begin<G>(fp, s, u, v, sample, ts));
                         }
                     }
                 }
@@ -489,23 +537,25 @@ __global__ __launch_bounds__(64 * VRT_POOL_WAVES, VRT_POOL_MIN_WAVES) __attribut
 }
 
 // ---- spatial reuse ---------------------------------------------------------------------------
-template <bool INSTR>
+template <int G, bool INSTR>
 #ifndef VRT_GRIS_MIN_WAVES
 #define VRT_GRIS_MIN_WAVES 2   // 256 registers, no spills; one wave per SIMD left the VALU idle a third of the time (6.6 vs 10.2 ms)
 #endif
 __global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES) void k_gris(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r1, int tiles_x, int band_w) {
-    __shared__ unsigned long long s_l1[512];
-    __shared__ unsigned long long s_l2[8];
+    constexpr int N1 = GridDim<G>::n1 * GridDim<G>::n1 * GridDim<G>::n1, N2 = GridDim<G>::n2 * GridDim<G>::n2 * GridDim<G>::n2;
+    __shared__ unsigned long long s_l1[N1];
+    __shared__ unsigned long long s_l2[N2];
     __shared__ float s_mats[128 * 14];
     __shared__ float s_mats_x[128 * 8];
     __shared__ float s_cs[4][64];          // per wave (= 8x8 pixel tile): cos / sin of the 32 tap angles
     __shared__ uint16_t s_off[32][256];    // per tap, per thread: the tap's pixel offset
-    for (int i = threadIdx.x; i < 512; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
-    if (threadIdx.x < 8) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
+    for (int i = threadIdx.x; i < N1; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
+    if (threadIdx.x < N2) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
     for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
     for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) s_mats_x[i] = gb.mats_x[i];
-    LdsPyramid P;
+    LdsPyramid<G> P;
     P.l0 = sc.pyr.l0; P.l1 = s_l1; P.l2 = s_l2;
+    P.w3 = (G == 256) ? sc.pyr.l3[0] : 0ULL;
     SceneData scl = sc;
     scl.mats = s_mats;
     GrisBuffers gbl = gb;
@@ -601,32 +651,39 @@ __global__ void k_detmath_probe(int op, int n, const float* a, const float* b, f
 // ---- host-side launchers -----------------------------------------------------------------------
 #define VRT_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
-hipError_t launch_prepare(hipStream_t st, const int8_t* mat, const uint8_t* rgb, uint32_t* grid, unsigned long long* l0,
-                          unsigned long long* l1, unsigned long long* l2, unsigned long long* l0c, uint32_t* l0c_base) {
-    const int n = VRT_GRID * VRT_GRID * VRT_GRID;
-    hipLaunchKernelGGL(k_pack_grid, dim3((n + 255) / 256), dim3(256), 0, st, mat, rgb, grid, n);
+hipError_t launch_prepare(hipStream_t st, int G, const int8_t* mat, const uint8_t* rgb, uint32_t* grid, unsigned long long* l0,
+                          unsigned long long* l1, unsigned long long* l2, unsigned long long* l3, unsigned long long* l0c, uint32_t* l0c_base) {
+    const int n = G * G * G, n0 = G / 4, n1 = G / 16, n2 = G / 64;
+    if (G == 256) hipLaunchKernelGGL(k_pack_grid<256>, dim3((n + 255) / 256), dim3(256), 0, st, mat, rgb, grid);
+    else hipLaunchKernelGGL(k_pack_grid<128>, dim3((n + 255) / 256), dim3(256), 0, st, mat, rgb, grid);
     VRT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_build_l0, dim3(32 * 32 * 32 / 256), dim3(256), 0, st, mat, l0);
+    hipLaunchKernelGGL(k_build_l0, dim3((n0 * n0 * n0 + 255) / 256), dim3(256), 0, st, mat, l0, G);
     VRT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_build_coarse, dim3(2), dim3(256), 0, st, (const unsigned long long*)l0, l1, 8);
+    hipLaunchKernelGGL(k_build_coarse, dim3((n1 * n1 * n1 + 255) / 256), dim3(256), 0, st, (const unsigned long long*)l0, l1, n1);
     VRT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_build_coarse, dim3(1), dim3(64), 0, st, (const unsigned long long*)l1, l2, 2);
+    hipLaunchKernelGGL(k_build_coarse, dim3(1), dim3(64), 0, st, (const unsigned long long*)l1, l2, n2);
     VRT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_build_l0c, dim3(1), dim3(512), 0, st, (const unsigned long long*)l0, (const unsigned long long*)l1, l0c, l0c_base);
+    if (G == 256) {  // the top word: bit = l2 word non-zero
+        hipLaunchKernelGGL(k_build_coarse, dim3(1), dim3(64), 0, st, (const unsigned long long*)l2, l3, 1);
+    } else {         // the compacted fine level of the pooled kernel's LDS copy (128^3 only)
+        hipLaunchKernelGGL(k_build_l0c, dim3(1), dim3(512), 0, st, (const unsigned long long*)l0, (const unsigned long long*)l1, l0c, l0c_base);
+    }
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
 
-template <bool RESTIR, bool INSTR>
-static hipError_t render_blocks_per_cu(int* out) {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, k_render<RESTIR, INSTR>, VRT_RENDER_THREADS, 0);
-}
-hipError_t query_render_residency(bool restir, bool instr, int* blocks_per_cu) {
-    if (restir) return instr ? render_blocks_per_cu<true, true>(blocks_per_cu) : render_blocks_per_cu<true, false>(blocks_per_cu);
-    return instr ? render_blocks_per_cu<false, true>(blocks_per_cu) : render_blocks_per_cu<false, false>(blocks_per_cu);
+// Kernel variants are picked by four switches; these macros spell the dispatch once.
+#define VRT_BY_GRID(G_, CALL) do { if ((G_) == 256) { constexpr int G = 256; CALL; } else { constexpr int G = 128; CALL; } } while (0)
+#define VRT_BY_2(A_, B_, CALL) do { if (A_) { constexpr bool A = true; if (B_) { constexpr bool B = true; CALL; } else { constexpr bool B = false; CALL; } } \
+                                    else { constexpr bool A = false; if (B_) { constexpr bool B = true; CALL; } else { constexpr bool B = false; CALL; } } } while (0)
+
+hipError_t query_render_residency(int grid_res, bool restir, bool instr, int* blocks_per_cu) {
+    hipError_t e = hipSuccess;
+    VRT_BY_GRID(grid_res, VRT_BY_2(restir, instr, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render<G, A, B>, VRT_RENDER_THREADS, 0)));
+    return e;
 }
 
-hipError_t launch_render(hipStream_t st, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
+hipError_t launch_render(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                          const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples) {
     // four sets of heads rotate: launch k counts on set k % 4 and zeroes set (k + 2) % 4 -- launches k and k + 1 may
     // overlap (vrt_accumulate), so neither the set in use nor the next one may be touched; set k + 1 was zeroed by launch k - 1
@@ -638,34 +695,27 @@ hipError_t launch_render(hipStream_t st, bool restir, bool instr, int n_blocks, 
     // is what the dense 4K frame needed (67 -> 22 dequeues/us, 5.9 -> 4.8 ms).  VRT_CHUNK overrides for experiments.
     unsigned chunk = 64u;
     if (const char* e = getenv("VRT_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 4096) chunk = (unsigned)(v / 64 * 64); }
-    if (restir) {
-        if (instr) hipLaunchKernelGGL((k_render<true, true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk, n_samples);
-        else hipLaunchKernelGGL((k_render<true, false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk, n_samples);
-    } else {
-        if (instr) hipLaunchKernelGGL((k_render<false, true>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk, n_samples);
-        else hipLaunchKernelGGL((k_render<false, false>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk, n_samples);
-    }
+    VRT_BY_GRID(grid_res, VRT_BY_2(restir, instr, hipLaunchKernelGGL((k_render<G, A, B>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk, n_samples)));
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t query_render_pool_residency(bool instr, int* blocks_per_cu) {
-    return instr ? hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool<true, false>, 64 * VRT_POOL_WAVES, 0)
-                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool<false, false>, 64 * VRT_POOL_WAVES, 0);
+int pool_waves_per_block(int grid_res) { return grid_res == 256 ? PoolGeom<256>::waves : PoolGeom<128>::waves; }
+hipError_t query_render_pool_residency(int grid_res, bool instr, int* blocks_per_cu) {
+    hipError_t e = hipSuccess;
+    VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool<G, A, B>, 64 * PoolGeom<G>::waves, 0)));
+    return e;
 }
-size_t pool_scratch_bytes(int n_blocks) { return (size_t)n_blocks * VRT_POOL_WAVES * VRT_POOL_SLOTS * PC_COUNT * sizeof(uint32_t); }
-hipError_t launch_render_pool(hipStream_t st, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
+size_t pool_scratch_bytes(int grid_res, int n_blocks) { return (size_t)n_blocks * pool_waves_per_block(grid_res) * VRT_POOL_SLOTS * PC_COUNT * sizeof(uint32_t); }
+hipError_t launch_render_pool(hipStream_t st, int grid_res, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                               const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold,
                               uint32_t* drain_signal, PrimaryRecord* prim_cache) {
     unsigned* work_counter = work_counters + (launch_seq & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     unsigned* next_counter = work_counters + ((launch_seq + 2u) & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
-    dim3 g(n_blocks), b(64 * VRT_POOL_WAVES);
+    dim3 g(n_blocks), b(64 * pool_waves_per_block(grid_res));
     // the signal carries launch_seq + 1 of the latest launch that has begun to drain
     // the black-sun variant (scene.py's default light) compiles the light sample out of the shading stage
     const bool black_sun = !((fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f);
-#define VRT_LAUNCH_POOL(I, B) hipLaunchKernelGGL((k_render_pool<I, B>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u, prim_cache)
-    if (instr) { if (black_sun) VRT_LAUNCH_POOL(true, true); else VRT_LAUNCH_POOL(true, false); }
-    else { if (black_sun) VRT_LAUNCH_POOL(false, true); else VRT_LAUNCH_POOL(false, false); }
-#undef VRT_LAUNCH_POOL
+    VRT_BY_GRID(grid_res, VRT_BY_2(instr, black_sun, hipLaunchKernelGGL((k_render_pool<G, A, B>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u, prim_cache)));
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -674,12 +724,11 @@ hipError_t launch_mat_derived(hipStream_t st, const float* mats, float* mats_x) 
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_gris(hipStream_t st, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1) {
+hipError_t launch_gris(hipStream_t st, int grid_res, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1) {
     hipLaunchKernelGGL(k_gris_prepare, dim3((fp.W + 63) / 64, (fp.row1 - fp.row0 + 3) / 4), dim3(256), 0, st, fp, sc, gb);
     const int tiles_x = (fp.W + 15) / 16, tiles_y = (r1 - r0 + 15) / 16, band_w = (tiles_x + 7) / 8;
     dim3 g(8 * band_w * tiles_y), b(256);
-    if (instr) hipLaunchKernelGGL((k_gris<true>), g, b, 0, st, fp, sc, gb, r0, r1, tiles_x, band_w);
-    else hipLaunchKernelGGL((k_gris<false>), g, b, 0, st, fp, sc, gb, r0, r1, tiles_x, band_w);
+    VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_gris<G, A>), g, b, 0, st, fp, sc, gb, r0, r1, tiles_x, band_w)));
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -88,8 +88,9 @@ VRT_DEV void walk_store_constants(const SlotRef& s, const RayWalk& w) {
     s.sf(PF_FAR, w.far);
     s.sv(PF_INV, w.inv_dir);
 }
+template <int G>
 VRT_DEV void walk_load(const SlotRef& s, RayWalk& w) {
-    w.o = world_to_voxel(s.v(PF_POS));
+    w.o = world_to_voxel<G>(s.v(PF_POS));
     w.d = s.v(PF_DIR);
     w.sd = mk3(sgn(w.d.x), sgn(w.d.y), sgn(w.d.z));
     w.inv_dir = s.v(PF_INV);
@@ -97,7 +98,7 @@ VRT_DEV void walk_load(const SlotRef& s, RayWalk& w) {
     w.far = s.f(PF_FAR);
     const uint32_t a = s.u(PF_CELL_XY), b = s.u(PF_CELL_Z);
     w.ix = (int)(int16_t)(a & 0xffffu); w.iy = (int)(int16_t)(a >> 16); w.iz = (int)(int16_t)(b & 0xffffu);
-    w.lod = (int)((b >> 16) & 7u);
+    w.lod = (int)((b >> 16) & 7u);   // LOD 0..7
     w.hn = normal_decode(b >> 20);
     w.iters = (int)s.u(PF_ITERS);
 }
@@ -154,21 +155,23 @@ VRT_DEV void path_load_cold(const uint32_t* line, Path<RESTIR>& p) {
 
 // What becomes of a closest-hit ray that ended at distance t (voxel units) given the floor distance of its path
 // (the comparison of hit_voxel(), pathtracer.py:203-204).
+template <int G>
 VRT_DEV int slot_state_after_walk(float t, float floor_t) {
-    return (t * (1.0f / 64.0f) < floor_t || floor_t < DM_INF) ? SLOT_SHADE : SLOT_ESCAPE;
+    return (t * GridDim<G>::voxel_size < floor_t || floor_t < DM_INF) ? SLOT_SHADE : SLOT_ESCAPE;
 }
 
 // Set up the closest-hit ray of the path in `s` (its pos and dir are stored already): floor distance and the
 // prepared walk.  A ray that misses the grid box has nothing to walk and goes straight to SHADE / ESCAPE.
+template <int G>
 VRT_DEV int pool_launch_ray(const FrameParams& fp, const SlotRef& s, f3 pos, f3 d, TraceStats& ts) {
     const float ft = floor_probe(fp, pos, d);
     s.sf(PF_FLOOR_T, ft);
     RayWalk w;
-    const bool alive = walk_prepare(world_to_voxel(pos), d, w);
+    const bool alive = walk_prepare<G>(world_to_voxel<G>(pos), d, w);
     ts.rays += 1u;
     walk_store(s, w);
     walk_store_constants(s, w);
-    return alive ? SLOT_RAY : slot_state_after_walk(w.t, ft);
+    return alive ? SLOT_RAY : slot_state_after_walk<G>(w.t, ft);
 }
 
 // The samples fused into one launch share camera and jitter, so a pixel's camera ray -- three quarters of all DDA
@@ -183,6 +186,7 @@ VRT_DEV PrimaryRecord primary_record(const SlotRef& s, uint32_t tag) {
     r.x = s.u(PF_T); r.y = s.u(PF_CELL_XY); r.z = s.u(PF_CELL_Z); r.w = tag;
     return r;
 }
+template <int G>
 VRT_DEV int pool_begin_known(const FrameParams& fp, const SlotRef& s, int u, int v, int sample, PrimaryRecord rec) {
     Path<false> p;
     path_begin(fp, p, u, v, sample);
@@ -190,15 +194,16 @@ VRT_DEV int pool_begin_known(const FrameParams& fp, const SlotRef& s, int u, int
     const float ft = floor_probe(fp, p.pos, p.d);
     s.sf(PF_FLOOR_T, ft);
     s.su(PF_T, rec.x); s.su(PF_CELL_XY, rec.y); s.su(PF_CELL_Z, rec.z); s.su(PF_ITERS, 0u);
-    return slot_state_after_walk(dm_u2f(rec.x), ft);
+    return slot_state_after_walk<G>(dm_u2f(rec.x), ft);
 }
 
 // BEGIN: work item (u, v, sample) -> camera ray pending.
+template <int G>
 VRT_DEV int pool_begin(const FrameParams& fp, const SlotRef& s, int u, int v, int sample, TraceStats& ts) {
     Path<false> p;
     path_begin(fp, p, u, v, sample);
     path_store_hot(s, p);
-    return pool_launch_ray(fp, s, p.pos, p.d, ts);
+    return pool_launch_ray<G>(fp, s, p.pos, p.d, ts);
 }
 
 // SHADE (KIND = HIT_SOMETHING) and ESCAPE (KIND = HIT_NOTHING): rebuild the closest hit from the slot, run the
@@ -219,7 +224,7 @@ VRT_DEV int pool_shade(const FrameParams& fp, const SceneData& sc, const PyrT& P
         TraceOut tr;
         walk_result(p.d, s.f(PF_T), (int)(int16_t)(a & 0xffffu), (int)(int16_t)(a >> 16), (int)(int16_t)(b & 0xffffu),
                     normal_decode(b >> 20), (int)s.u(PF_ITERS), tr);
-        hit_voxel<false>(fp, sc, world_to_voxel(p.pos), p.d, tr, h, ts);
+        hit_voxel<false, PyrT::G>(fp, sc, world_to_voxel<PyrT::G>(p.pos), p.d, tr, h, ts);
     }
     const bool done = path_shade<false, KIND, BLACK_SUN>(fp, sc, P, out, local_idx, p, h, ts);
     if (done) {
@@ -229,7 +234,7 @@ VRT_DEV int pool_shade(const FrameParams& fp, const SceneData& sc, const PyrT& P
     }
     if (depth == 0) path_store_cold(cold_line, p);
     path_store_hot(s, p);
-    return pool_launch_ray(fp, s, p.pos, p.d, ts);
+    return pool_launch_ray<PyrT::G>(fp, s, p.pos, p.d, ts);
 }
 
 }  // namespace vrt

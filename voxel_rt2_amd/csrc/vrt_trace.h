@@ -1,4 +1,4 @@
-// vrt_trace.h -- hierarchical DDA over the 128^3 voxel grid and the closest-hit query.
+// vrt_trace.h -- hierarchical DDA over the G^3 voxel grid (G = 128 or 256, vrt_types.h) and the closest-hit query.
 //
 // Replaces VoxelOctreeRaytracer.raytrace / query_occupancy (reference renderer/raytracer.py:40-44,
 // 72-155), VoxelWorld.voxel_surface_color (voxel_world.py:34-56) and Renderer._trace_sdf /
@@ -7,7 +7,7 @@
 // Same walk, different machine mapping.  The reference keeps one bit per cell per LOD in a flat
 // i32 array and issues one dependent 4-byte load per LOD it descends (up to 7 per DDA step).
 // Here occupancy lives in 4x4x4 bit bricks (Pyramid, vrt_types.h): ONE 64-bit word answers three
-// LODs at once, the two coarse brick levels (4 KiB + 64 B) sit in LDS, and the fine brick word of
+// LODs at once, the coarse brick levels (4 KiB + 64 B at 128^3, 32 KiB + 512 B + one word at 256^3) sit in LDS, and the fine brick word of
 // the cell a ray is in stays in registers across DDA steps, so a step that remains inside its
 // brick issues no memory instruction at all.  The sequence of (cell, LOD) states a ray visits --
 // and with it every float the reference computes -- is unchanged: descend() returns the state the
@@ -21,7 +21,7 @@ namespace vrt {
 
 struct SceneData {
     Pyramid pyr;
-    const uint32_t* grid;   // rgba8 texel per voxel, [x][y][z] (voxel_world.py:76-87 holds the same bytes)
+    const uint32_t* grid;   // rgba8 texel per voxel (voxel_world.py:76-87 holds the same bytes), order: texel_index()
     const float* mats;      // [128][14]
     SkyTables sky;
     Counters* counters;     // instrumented build only
@@ -34,29 +34,44 @@ VRT_DEV unsigned long long brick_sub(int cx, int cy, int cz) {  // the 2x2x2 blo
     return 0x0000000000330033ULL << (((cz & 2) << 4) | ((cy & 2) << 2) | (cx & 2));
 }
 
+// Where the texel of voxel (x,y,z) sits.  128^3 (8 MiB, cache resident): [x][y][z], the reference's storage order.
+// 256^3 (64 MiB: beyond the L2s): brick-tiled -- the 64 texels of a 4x4x4 brick are contiguous (two 128-byte lines), bricks
+// in l0 word order -- so that the hits of neighbouring pixels, which land on neighbouring voxels of a surface, share lines.
+template <int G>
+VRT_DEV int texel_index(int x, int y, int z) {
+    if (G == 128) return ((x << 7) | y) << 7 | z;
+    return (((((z >> 2) << 6) | (y >> 2)) << 6 | (x >> 2)) << 6) | brick_bit(x, y, z);
+}
+
 // Level the reference's descent ends at when it starts at `lod` on LOD-0 cell (x,y,z), and whether
 // it ended on a solid voxel.  `nq` receives the number of query_occupancy calls the reference
 // would have made (for the algorithmic-bytes counters).
 template <class PyrT>
 VRT_DEV int descend(const PyrT& P, int x, int y, int z, int lod, bool& solid, BrickCache& bc, int& nq) {
+    constexpr int G = PyrT::G;
+    typedef GridDim<G> D;
     solid = false;
     nq = 1;
-    if ((x | y | z) & ~(VRT_GRID - 1)) return lod;  // outside the grid: empty (UB in the reference)
+    if ((x | y | z) & ~(G - 1)) return lod;  // outside the grid: empty (UB in the reference)
     const int start = lod;
+    if (G == 256 && lod == 7) {  // the 2x2x2 block of 64^3 cells around the cell, from the top word
+        if ((P.load_l3() & brick_sub(x >> 6, y >> 6, z >> 6)) == 0ULL) return 7;
+        lod = 6;
+    }
     if (lod >= 4) {
-        unsigned long long w2 = P.load_l2((((z >> 6) << 1) | (y >> 6)) << 1 | (x >> 6));
-        if (lod == 6) { if (w2 == 0ULL) return 6; lod = 5; }
+        unsigned long long w2 = P.load_l2((((z >> 6) << D::s2) | (y >> 6)) << D::s2 | (x >> 6));
+        if (lod == 6) { if (w2 == 0ULL) { nq = start - 6 + 1; return 6; } lod = 5; }
         if (lod == 5) { if ((w2 & brick_sub(x >> 4, y >> 4, z >> 4)) == 0ULL) { nq = start - 5 + 1; return 5; } lod = 4; }
         if (((w2 >> brick_bit(x >> 4, y >> 4, z >> 4)) & 1ULL) == 0ULL) { nq = start - 4 + 1; return 4; }
         lod = 3;
     }
     if (lod >= 2) {
-        unsigned long long w1 = P.load_l1((((z >> 4) << 3) | (y >> 4)) << 3 | (x >> 4));
+        unsigned long long w1 = P.load_l1((((z >> 4) << D::s1) | (y >> 4)) << D::s1 | (x >> 4));
         if (lod == 3) { if ((w1 & brick_sub(x >> 2, y >> 2, z >> 2)) == 0ULL) { nq = start - 3 + 1; return 3; } lod = 2; }
         if (((w1 >> brick_bit(x >> 2, y >> 2, z >> 2)) & 1ULL) == 0ULL) { nq = start - 2 + 1; return 2; }
         lod = 1;
     }
-    const int key = (((z >> 2) << 5) | (y >> 2)) << 5 | (x >> 2);
+    const int key = (((z >> 2) << D::s0) | (y >> 2)) << D::s0 | (x >> 2);
     if (key != bc.key) { bc.key = key; bc.word = P.load_l0(key); }
     const unsigned long long w0 = bc.word;
     if (lod == 1) { if ((w0 & brick_sub(x, y, z)) == 0ULL) { nq = start - 1 + 1; return 1; } }
@@ -84,8 +99,11 @@ struct CoarseWords { unsigned long long w1, w2; uint32_t fine_base; };
 // the WALK loop asks for the next cell's context at the end of a step and meets it a step later.
 template <class PyrT>
 VRT_DEV void coarse_fetch(const PyrT& P, int x, int y, int z, CoarseWords& c) {
-    const int xm = x & (VRT_GRID - 1), ym = y & (VRT_GRID - 1), zm = z & (VRT_GRID - 1);  // keeps the table index in range
-    P.load_coarse((((zm >> 4) << 3) | (ym >> 4)) << 3 | (xm >> 4), c.w1, c.w2, c.fine_base);
+    constexpr int G = PyrT::G;
+    typedef GridDim<G> D;
+    const int xm = x & (G - 1), ym = y & (G - 1), zm = z & (G - 1);  // keeps the table index in range
+    P.load_coarse((((zm >> 4) << D::s1) | (ym >> 4)) << D::s1 | (xm >> 4), (((zm >> 6) << D::s2) | (ym >> 6)) << D::s2 | (xm >> 6),
+                  c.w1, c.w2, c.fine_base);
 }
 
 // descend() without the walk: same result, fixed cost.  descend() is a seven-way nest of branches; a wave whose
@@ -98,14 +116,17 @@ VRT_DEV void coarse_fetch(const PyrT& P, int x, int y, int z, CoarseWords& c) {
 // which is where the compacted fine level keeps it (load_fine; a pyramid without one just indexes l0 by `key`).
 template <class PyrT>
 VRT_DEV int descend_flat(const PyrT& P, const CoarseWords& c, int x, int y, int z, int lod, bool& solid, BrickCache& bc, int& nq) {
-    const bool inside = ((x | y | z) & ~(VRT_GRID - 1)) == 0;  // outside the grid: empty, as in descend()
-    const int xm = x & (VRT_GRID - 1), ym = y & (VRT_GRID - 1), zm = z & (VRT_GRID - 1);
+    constexpr int G = PyrT::G;
+    typedef GridDim<G> D;
+    const bool inside = ((x | y | z) & ~(G - 1)) == 0;  // outside the grid: empty, as in descend()
+    const int xm = x & (G - 1), ym = y & (G - 1), zm = z & (G - 1);
     unsigned occ = (c.w2 != 0ULL ? 64u : 0u) | (brick_two_lods(c.w2, xm >> 4, ym >> 4, zm >> 4) << 4) |
                    (brick_two_lods(c.w1, xm >> 2, ym >> 2, zm >> 2) << 2);
+    if (G == 256) occ |= (P.load_l3() & brick_sub(xm >> 6, ym >> 6, zm >> 6)) != 0ULL ? 128u : 0u;  // LOD 7 (LOD 6 = its bit = w2 != 0)
     const unsigned upto = (2u << lod) - 1u;  // levels 0..lod
     // the fine brick word matters only when every level from `lod` down to 2 is occupied
     if (inside && (~occ & upto & ~3u) == 0u) {
-        const int key = (((zm >> 2) << 5) | (ym >> 2)) << 5 | (xm >> 2);
+        const int key = (((zm >> 2) << D::s0) | (ym >> 2)) << D::s0 | (xm >> 2);
         VRT_REGION(19);
         if (key != bc.key) {
             VRT_REGION(18);
@@ -124,17 +145,21 @@ VRT_DEV int descend_flat(const PyrT& P, const CoarseWords& c, int x, int y, int 
     return level;
 }
 
-struct GlobalPyramid {  // all three brick levels read from global memory
+template <int G_>
+struct GlobalPyramid {  // all brick levels read from global memory
+    static constexpr int G = G_;
     static constexpr bool flat_descend = false;
     Pyramid p;
     VRT_DEV unsigned long long load_l0(int i) const { return p.l0[i]; }
     VRT_DEV unsigned long long load_l1(int i) const { return p.l1[i]; }
     VRT_DEV unsigned long long load_l2(int i) const { return p.l2[i]; }
-    VRT_DEV unsigned long long load_fine(int key, uint32_t idx) const { (void)key; return p.l0c[idx]; }
-    VRT_DEV void load_coarse(int i1, unsigned long long& w1, unsigned long long& w2, uint32_t& fine_base) const {
+    VRT_DEV unsigned long long load_l3() const { return p.l3[0]; }
+    VRT_DEV unsigned long long load_fine(int key, uint32_t idx) const { return G == 128 ? p.l0c[idx] : p.l0[key]; }
+    // i1 / i2: the l1 word of the cell and the l2 word holding it
+    VRT_DEV void load_coarse(int i1, int i2, unsigned long long& w1, unsigned long long& w2, uint32_t& fine_base) const {
         w1 = p.l1[i1];
-        w2 = p.l2[(((i1 >> 8) & 1) << 2) | (((i1 >> 5) & 1) << 1) | ((i1 >> 2) & 1)];  // the l2 brick holding l1 brick i1
-        fine_base = p.l0c_base[i1];
+        w2 = p.l2[i2];
+        fine_base = G == 128 ? p.l0c_base[i1] : 0u;
     }
 };
 
@@ -148,9 +173,10 @@ VRT_DEV void raytrace(const PyrT& P, f3 o, f3 d, TraceOut& r, int& queries) {
     f3 hn = mk3(0.0f);
     int iters = 0;
     queries = 0;
-    const float res = (float)VRT_GRID;
+    constexpr int G = PyrT::G;
+    const float res = (float)G;
 
-    // math_utils.py:103-123 against the box [0,128]^3
+    // math_utils.py:103-123 against the box [0,G]^3
     float near_t = -DM_INF, far_t = DM_INF;
 #define VRT_SLAB(oc, dc)                                                     \
     if (dc != 0.0f) {                                                        \
@@ -207,7 +233,7 @@ VRT_DEV void raytrace(const PyrT& P, f3 o, f3 d, TraceOut& r, int& queries) {
             hn = mk3(t.x == min_t ? 1.0f : 0.0f, t.y == min_t ? 1.0f : 0.0f, t.z == min_t ? 1.0f : 0.0f) * sd;
             const f3 nxt = cell_base + edge + hn;
             ix = (int)nxt.x; iy = (int)nxt.y; iz = (int)nxt.z;
-            lod = (lod + 1 > 6) ? 6 : lod + 1;
+            lod = (lod + 1 > GridDim<G>::max_lod) ? GridDim<G>::max_lod : lod + 1;
             iters += 1;
         }
     }
@@ -230,6 +256,7 @@ struct RayWalk {
 };
 
 // raytracer.py:81-101: clip against the grid box, first cell, entry-face normal.  False = the box is missed.
+template <int G>
 VRT_DEV bool walk_prepare(f3 o, f3 d, RayWalk& w) {
     w.o = o; w.d = d;
     w.sd = mk3(sgn(d.x), sgn(d.y), sgn(d.z));
@@ -237,7 +264,7 @@ VRT_DEV bool walk_prepare(f3 o, f3 d, RayWalk& w) {
     w.ix = -1; w.iy = -1; w.iz = -1; w.lod = 0; w.iters = 0;
     w.hn = mk3(0.0f);
     w.inv_dir = mk3(0.0f);
-    const float res = (float)VRT_GRID;
+    const float res = (float)G;
     float near_t = -DM_INF, far_t = DM_INF;
 #define VRT_SLAB(oc, dc)                                                     \
     if (dc != 0.0f) {                                                        \
@@ -293,7 +320,7 @@ VRT_DEV bool walk_trip(const PyrT& P, RayWalk& w, BrickCache& bc, CoarseWords& c
     const f3 nxt = cell_base + edge + w.hn;
     w.ix = (int)nxt.x; w.iy = (int)nxt.y; w.iz = (int)nxt.z;
     coarse_fetch(P, w.ix, w.iy, w.iz, c);
-    w.lod = (lod + 1 > 6) ? 6 : lod + 1;
+    w.lod = (lod + 1 > GridDim<PyrT::G>::max_lod) ? GridDim<PyrT::G>::max_lod : lod + 1;
     w.iters += 1;
     return false;
 }
@@ -338,11 +365,12 @@ VRT_DEV void hit_floor(const FrameParams& fp, f3 d, float t, Hit& h) {
     h.hit_light = (fp.floor_material == 2) ? 1 : 0;
     h.mat_id = fp.floor_material;
 }
-VRT_DEV f3 world_to_voxel(f3 pos) { return 64.0f * pos - (-64.0f); }  // pathtracer.py:165-171
+template <int G>
+VRT_DEV f3 world_to_voxel(f3 pos) { return GridDim<G>::half * pos - (-GridDim<G>::half); }  // pathtracer.py:165-171: voxel_inv_size * pos - voxel_grid_offset
 // pathtracer.py:203-216 + voxel_world.py:34-56: the walk's result against what is closest so far.  SHADOW: no surface lookup.
-template <bool SHADOW>
+template <bool SHADOW, int G>
 VRT_DEV void hit_voxel(const FrameParams& fp, const SceneData& sc, f3 eye, f3 d, const TraceOut& tr, Hit& h, TraceStats& ts) {
-    const float voxel_size = 1.0f / 64.0f;
+    const float voxel_size = GridDim<G>::voxel_size;
     if (tr.dist * voxel_size < h.closest) {
         h.closest = tr.dist * voxel_size;
         if (!SHADOW) {
@@ -356,8 +384,8 @@ VRT_DEV void hit_voxel(const FrameParams& fp, const SceneData& sc, f3 eye, f3 d,
             const float f = (cnt >= 2) ? 1.0f : 0.0f;
             f3 col = mk3(0.0f);
             int m = 0, light = 0;
-            if (((tr.ix | tr.iy | tr.iz) & ~(VRT_GRID - 1)) == 0) {
-                uint32_t texel = sc.grid[((tr.ix << 7) | tr.iy) << 7 | tr.iz];
+            if (((tr.ix | tr.iy | tr.iz) & ~(G - 1)) == 0) {
+                uint32_t texel = sc.grid[texel_index<G>(tr.ix, tr.iy, tr.iz)];
                 col = mk3((float)(texel & 255u) / 255.0f, (float)((texel >> 8) & 255u) / 255.0f,
                           (float)((texel >> 16) & 255u) / 255.0f);
                 float a = (float)(texel >> 24) / 255.0f;
@@ -378,13 +406,13 @@ VRT_DEV void next_hit(const FrameParams& fp, const SceneData& sc, const PyrT& P,
     hit_init(h);
     const float ft = floor_probe(fp, pos, d);
     if (ft < DM_INF) hit_floor(fp, d, ft, h);
-    const f3 eye = world_to_voxel(pos);
+    const f3 eye = world_to_voxel<PyrT::G>(pos);
     TraceOut tr;
     int nq;
     raytrace(P, eye, d, tr, nq);
     ts.rays += 1u; ts.iters += (unsigned)tr.iters; ts.queries += (unsigned)nq;
     VRT_REGION(SHADOW ? 3 : 9);  // ray set-up + result (one entry per ray)
-    hit_voxel<SHADOW>(fp, sc, eye, d, tr, h, ts);
+    hit_voxel<SHADOW, PyrT::G>(fp, sc, eye, d, tr, h, ts);
 }
 
 }  // namespace vrt

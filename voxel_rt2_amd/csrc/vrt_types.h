@@ -102,7 +102,23 @@ static __device__ unsigned long long g_vrt_region[64];
 #else
 #define VRT_REGION(id) ((void)0)
 #endif
-#define VRT_GRID 128
+
+// The voxel grid is G^3 cells, G = 128 (the reference's voxel_grid_res, pathtracer.py:83) or 256 (BASELINE config 5:
+// VoxelWorld / VoxelOctreeRaytracer are parametric in it -- n_lods = log2 G, raytracer.py:9; offset -G/2,
+// voxel_world.py:14).  G is a template parameter of everything that walks the grid, so the 128 kernels keep their
+// literal constants.  The world box stays [-1, 1]^3: voxel size dx = 2 / G (scene.py:11's 1/64 at G = 128).
+template <int G>
+struct GridDim {
+    static_assert(G == 128 || G == 256, "grid_res is 128 or 256");
+    static constexpr int lods = (G == 256) ? 8 : 7;      // raytracer.py:9
+    static constexpr int max_lod = lods - 1;             // raytracer.py:147
+    static constexpr int s0 = (G == 256) ? 6 : 5;        // log2 of the words per axis of brick level 0, 1, 2
+    static constexpr int s1 = s0 - 2;
+    static constexpr int s2 = s0 - 4;
+    static constexpr int n0 = 1 << s0, n1 = 1 << s1, n2 = 1 << s2;
+    static constexpr float half = (float)(G / 2);        // voxel_inv_size (= 1 / dx) and -voxel_grid_offset
+    static constexpr float voxel_size = 2.0f / (float)G; // dx
+};
 
 // One Disney material row (14 f32, the order of the host table).
 struct Material {
@@ -114,18 +130,21 @@ struct Material {
 // Traversal counters of the instrumented build (one slot per counter, atomically summed).
 struct Counters { unsigned long long rays, iters, queries, closest_hits, sky_lookups; };
 
-// Occupancy pyramid as three levels of 4x4x4 bit bricks (64-bit words):
-//   l0[32^3]: bit = voxel solid          -> LOD 0 (bit), LOD 1 (2x2x2 sub-mask), LOD 2 (word != 0)
-//   l1[ 8^3]: bit = l0 word non-zero     -> LOD 2 (bit), LOD 3 (sub-mask),       LOD 4 (word != 0)
-//   l2[ 2^3]: bit = l1 word non-zero     -> LOD 4 (bit), LOD 5 (sub-mask),       LOD 6 (word != 0)
+// Occupancy pyramid as levels of 4x4x4 bit bricks (64-bit words), n_k = G / 4^(k+1) words per axis:
+//   l0[n0^3]: bit = voxel solid          -> LOD 0 (bit), LOD 1 (2x2x2 sub-mask), LOD 2 (word != 0)
+//   l1[n1^3]: bit = l0 word non-zero     -> LOD 2 (bit), LOD 3 (sub-mask),       LOD 4 (word != 0)
+//   l2[n2^3]: bit = l1 word non-zero     -> LOD 4 (bit), LOD 5 (sub-mask),       LOD 6 (word != 0)
+//   l3[1]   : bit = l2 word non-zero     -> LOD 6 (bit), LOD 7 (sub-mask)        (G = 256 only: 32^3 / 8^3 / 2^3 words
+//                                                                                 at 128, 64^3 / 16^3 / 4^3 / 1 at 256)
 // Word index inside a level: (bz * n + by) * n + bx; bit inside a word: (z&3)*16 + (y&3)*4 + (x&3).
-// l0c is l0 without its empty words: the non-zero fine words in (l1 brick, bit) order, i.e. the word of the l0
+// l0c (G = 128) is l0 without its empty words: the non-zero fine words in (l1 brick, bit) order, i.e. the word of the l0
 // brick behind set bit b of l1 word i sits at l0c[l0c_base[i] + popcount(l1[i] & ((1 << b) - 1))].  A sparse scene's
 // whole fine level is then a few KB and the pooled render kernel keeps (the head of) it in LDS.
 struct Pyramid {
     const unsigned long long* l0;
     const unsigned long long* l1;
     const unsigned long long* l2;
+    const unsigned long long* l3;   // [1], G = 256
     const unsigned long long* l0c;
     const uint32_t* l0c_base;   // [512]
     const uint32_t* l0c_count;  // [1]: non-empty l0 words

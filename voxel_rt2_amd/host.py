@@ -6,9 +6,11 @@ from . import _abi, camera as cam_mod
 
 
 def make_config(width, height, *, voxel_edges=0.06, exposure=3.0, max_depth=4, use_restir=False, seed=0, sky_res=0,
-                device=0, rows=None, dx=1.0 / 64.0):
+                device=0, rows=None, dx=None, grid_res=128):
     cfg = _abi.VrtConfig()
-    cfg.width, cfg.height, cfg.grid_res = int(width), int(height), 128
+    cfg.width, cfg.height, cfg.grid_res = int(width), int(height), int(grid_res)
+    if dx is None:
+        dx = 2.0 / int(grid_res)   # the grid spans [-1,1]^3: scene.py:11's 1/64 at 128
     cfg.dx, cfg.voxel_edges, cfg.exposure = float(dx), float(voxel_edges), float(exposure)
     cfg.max_depth, cfg.use_restir, cfg.seed = int(max_depth), int(bool(use_restir)), int(seed) & 0xFFFFFFFF
     cfg.sky_res, cfg.device = int(sky_res), int(device)

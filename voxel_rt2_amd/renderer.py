@@ -48,21 +48,25 @@ def _f32(x):
 
 class VoxelStore:
     """Renderer.set_voxel / get_voxel and their storage (pathtracer.py:1325-1334, voxel_world.py:7-18):
-    int8 material + uint8 rgb per voxel, index (x+64, y+64, z+64).  Kept on the host because the example
-    kernels author the scene on the host; bytearray-backed so a per-voxel call costs ~1 us."""
+    int8 material + uint8 rgb per voxel, index (x+G/2, y+G/2, z+G/2), G = voxel_grid_res (128 in the reference,
+    pathtracer.py:83).  Kept on the host because the example kernels author the scene on the host; bytearray-backed
+    so a per-voxel call costs ~1 us."""
 
-    def _init_voxels(self):
-        self._mat = bytearray(128 * 128 * 128)
-        self._rgb = bytearray(128 * 128 * 128 * 3)
-        self.voxel_material = np.frombuffer(self._mat, dtype=np.int8).reshape(128, 128, 128)
-        self.voxel_color = np.frombuffer(self._rgb, dtype=np.uint8).reshape(128, 128, 128, 3)
+    def _init_voxels(self, grid_res=128):
+        g = self.voxel_grid_res = int(grid_res)
+        self._mat = bytearray(g * g * g)
+        self._rgb = bytearray(g * g * g * 3)
+        self.voxel_material = np.frombuffer(self._mat, dtype=np.int8).reshape(g, g, g)
+        self.voxel_color = np.frombuffer(self._rgb, dtype=np.uint8).reshape(g, g, g, 3)
         self._voxels_dirty = True
 
     def set_voxel(self, idx, mat, color):
-        x, y, z = int(idx[0]) + 64, int(idx[1]) + 64, int(idx[2]) + 64
-        if not (0 <= x < 128 and 0 <= y < 128 and 0 <= z < 128):
+        g = self.voxel_grid_res
+        h = g >> 1
+        x, y, z = int(idx[0]) + h, int(idx[1]) + h, int(idx[2]) + h
+        if not (0 <= x < g and 0 <= y < g and 0 <= z < g):
             return  # the reference writes out of bounds here (undefined behaviour)
-        i = (x * 128 + y) * 128 + z
+        i = (x * g + y) * g + z
         self._mat[i] = int(mat) & 0xFF  # ti.cast(mat, ti.i8)
         rgb = self._rgb
         j = 3 * i
@@ -73,10 +77,12 @@ class VoxelStore:
         self._voxels_dirty = True
 
     def get_voxel(self, ijk):
-        x, y, z = int(ijk[0]) + 64, int(ijk[1]) + 64, int(ijk[2]) + 64
-        if not (0 <= x < 128 and 0 <= y < 128 and 0 <= z < 128):
+        g = self.voxel_grid_res
+        h = g >> 1
+        x, y, z = int(ijk[0]) + h, int(ijk[1]) + h, int(ijk[2]) + h
+        if not (0 <= x < g and 0 <= y < g and 0 <= z < g):
             return 0, (0.0, 0.0, 0.0)
-        i = (x * 128 + y) * 128 + z
+        i = (x * g + y) * g + z
         m = self._mat[i]
         j = 3 * i
         return (m - 256 if m > 127 else m), (_f32(self._rgb[j] / 255.0), _f32(self._rgb[j + 1] / 255.0), _f32(self._rgb[j + 2] / 255.0))
@@ -89,7 +95,7 @@ class VoxelStore:
 
 class Renderer(VoxelStore):
     def __init__(self, dx, image_res, up, voxel_edges, exposure=3, *, max_depth=None, use_restir=None, seed=None, sky_res=None,
-                 device=0, rows=None):
+                 device=0, rows=None, grid_res=None):
         self.image_res = tuple(int(x) for x in image_res)
         self.aspect_ratio = self.image_res[0] / self.image_res[1]
         self.exposure = exposure
@@ -100,11 +106,12 @@ class Renderer(VoxelStore):
         self.sky_res = int(os.environ.get("VRT_SKY_RES", 3840)) if sky_res is None else int(sky_res)
         cfg = host.make_config(self.image_res[0], self.image_res[1], voxel_edges=voxel_edges, exposure=exposure,
                                max_depth=self.max_depth, use_restir=self.use_restir, seed=self.seed, sky_res=self.sky_res,
-                               device=device, rows=rows, dx=dx)
-        self._s = NativeSession(_lib.load(), "vrt_", cfg)
+                               device=device, rows=rows, dx=dx,
+                               grid_res=int(os.environ.get("VRT_GRID_RES", 128)) if grid_res is None else int(grid_res))
+        self._s = NativeSession(_lib.load(), "vrt_", cfg)   # the library insists on dx == 2 / grid_res
 
         # voxel storage the user kernels write through set_voxel (voxel_world.py:7-18)
-        self._init_voxels()
+        self._init_voxels(cfg.grid_res)
 
         dirty = self._mark_scene_dirty
         self.floor_height = _Field(0.0, dirty)       # pathtracer.py:91-93

@@ -1,7 +1,8 @@
 """Deterministic synthetic voxel scenes for tests and bench.py.
 
-Every builder returns ``(mat int8[128,128,128], rgb uint8[128,128,128,3], params dict)`` with
-arrays indexed ``[x+64, y+64, z+64]`` -- the storage of voxel_world.py:14-18.  Colours follow
+Every builder returns ``(mat int8[G,G,G], rgb uint8[G,G,G,3], params dict)`` with arrays indexed
+``[x+G/2, y+G/2, z+G/2]`` -- the storage of voxel_world.py:14-18; G = 128 (the reference's grid) unless the
+builder says otherwise (BASELINE config 5 uses 256, with voxels of half the size: the world box stays [-1,1]^3).  Colours follow
 Renderer.set_voxel (pathtracer.py:1325-1328, math_utils.py:86-92): u8 = trunc(clamp(c,0,1)*255)
 evaluated in float32.  Randomness is a numpy PCG hash of the cell index, so a scene depends only
 on its seed.
@@ -30,8 +31,8 @@ def color_u8(c):
     return (c * np.float32(255.0)).astype(np.uint8)
 
 
-def empty():
-    return np.zeros((G, G, G), dtype=np.int8), np.zeros((G, G, G, 3), dtype=np.uint8)
+def empty(grid=G):
+    return np.zeros((grid, grid, grid), dtype=np.int8), np.zeros((grid, grid, grid, 3), dtype=np.uint8)
 
 
 def _set(mat, rgb, x, y, z, m, c):
@@ -87,8 +88,10 @@ def scene_sunlit(seed=0):
     return mat, rgb, params
 
 
-def scene_dense(seed=12345, occupancy=0.5):
-    """Config 4: every voxel solid with probability `occupancy`, material 1, random colour."""
+def scene_dense(seed=12345, occupancy=0.5, grid=128):
+    """Config 4 (grid 128) / config 5 (grid 256): every voxel solid with probability `occupancy`, material 1,
+    random colour."""
+    G = int(grid)
     idx = np.arange(G * G * G, dtype=np.uint64)
     solid = rand01(seed, idx * 4) < np.float32(occupancy)
     mat = solid.astype(np.int8).reshape(G, G, G)
@@ -168,4 +171,48 @@ def scene_s6(seed=0):
     return mat, rgb, params
 
 
-SCENES = {"s1": scene_s1, "sunlit": scene_sunlit, "dense": scene_dense, "s6": scene_s6}
+def upsample2(mat, rgb):
+    """The same scene on a grid of twice the resolution: every voxel becomes 2x2x2 voxels of half the size."""
+    m = np.repeat(np.repeat(np.repeat(mat, 2, axis=0), 2, axis=1), 2, axis=2)
+    c = np.repeat(np.repeat(np.repeat(rgb, 2, axis=0), 2, axis=1), 2, axis=2)
+    return np.ascontiguousarray(m), np.ascontiguousarray(c)
+
+
+def scene_s1_256(seed=0):
+    """Scene S1 refined to 256^3 (sparse: 0.17 % occupancy), same world geometry, voxel edges drawn per fine voxel."""
+    mat, rgb, params = scene_s1(seed)
+    mat, rgb = upsample2(mat, rgb)
+    return mat, rgb, params
+
+
+def scene_sponge256(seed=0):
+    """A level-5 Menger sponge (243^3 cells) centred in a 256^3 grid, sun-lit, a few emissive cells: occupancy that is
+    neither sparse nor uniformly dense -- holes at every scale of the brick pyramid, long walks through them."""
+    G, n = 256, 243
+    c = np.arange(n)
+    digits = np.stack([(c // 3 ** k) % 3 == 1 for k in range(5)], axis=0)      # [level][coord]: digit is 1
+    dx, dy, dz = digits[:, :, None, None], digits[:, None, :, None], digits[:, None, None, :]
+    hole = ((dx & dy) | (dx & dz) | (dy & dz)).any(axis=0)                    # two or more middle digits at some level
+    solid = ~hole
+    mat = np.zeros((G, G, G), dtype=np.int8)
+    rgb = np.zeros((G, G, G, 3), dtype=np.uint8)
+    o = (G - n) // 2
+    idx = np.arange(n * n * n, dtype=np.uint64).reshape(n, n, n)
+    r = rand01(seed, idx * 2)
+    m = np.where(r < np.float32(0.002), 2, np.where(r < np.float32(0.3), 11, 1)).astype(np.int8)
+    mat[o:o + n, o:o + n, o:o + n] = np.where(solid, m, 0)
+    col = np.stack([(pcg_hash(np.uint64(seed) + idx * 4 + k) & 0x7F).astype(np.uint8) + 96 for k in (1, 2, 3)], axis=-1)
+    rgb[o:o + n, o:o + n, o:o + n] = col * solid[..., None]
+    params = dict(exposure=1.0, voxel_edges=0.06, floor_height=-1.0, floor_color=(0.8, 0.8, 0.8), floor_material=1,
+                  background_color=(0.3, 0.4, 0.6), light_direction=(1.0, 1.0, 1.0), light_cone=0.1,
+                  light_color=(1.0, 1.0, 1.0), use_physical_sky=0, use_clouds=0)
+    return mat, rgb, params
+
+
+def scene_dense256(seed=12345, occupancy=0.5):
+    """Config 5's stress scene: the config-4 fill on the 256^3 grid (64 MiB of texels, 2 MiB of fine brick words)."""
+    return scene_dense(seed, occupancy, grid=256)
+
+
+SCENES = {"s1": scene_s1, "sunlit": scene_sunlit, "dense": scene_dense, "s6": scene_s6,
+          "s1_256": scene_s1_256, "sponge256": scene_sponge256, "dense256": scene_dense256}
