@@ -88,7 +88,10 @@ typedef struct vrt_stats {
     uint64_t rays, dda_iters, occupancy_queries, closest_hits, sky_lookups; /* instrumented build only, else 0 */
     double render_ms, temporal_ms, gris_ms;  /* summed device time of the kernels (hipEvent) */
     uint32_t render_launches, temporal_launches, gris_launches;
-    uint32_t pad;
+    uint32_t pipeline_flags;      /* bit 0: launches of consecutive vrt_accumulate calls overlap; bit 1: the next launch's dispatch
+                                     is held until the running one starts to drain (stream wait on a kernel-raised word; left out
+                                     where a self-test finds that queue operations are serialised, e.g. under rocprofv3 --pmc);
+                                     bits 8..31: times the host released that wait (error paths, synchronisation watchdog) */
 } vrt_stats;
 
 /* buffers readable through vrt_fetch_buffer (tests and the multi-GPU gather) */
@@ -151,10 +154,20 @@ int vrt_sync(vrt_ctx* ctx);
 int vrt_get_stats(vrt_ctx* ctx, vrt_stats* out);
 int vrt_reset_stats(vrt_ctx* ctx);
 const char* vrt_last_error(void);
+/* The render kernels are persistent: their grid fills every CU (two workgroups of 79 KB LDS each, or one of 148 KB at
+ * grid_res 256), so another kernel -- an RCCL collective of a multi-GPU run -- finds no workgroup slot until a launch
+ * drains.  This leaves n_cus CUs' worth of slots out of the grid (0 = none, the single-GPU default).  No counterpart in the
+ * reference (one GPU, pathtracer.py); voxel_rt2_amd/parallel.py calls it when the process group has more than one rank. */
+int vrt_reserve_cus(vrt_ctx* ctx, int n_cus);
 /* Select the kernel variants that count rays / DDA iterations / occupancy queries / hits
  * (vrt_stats.rays etc.); off by default -- the counters are what the reference's disabled
- * iteration heat-map (pathtracer.py:419-425) would have shown. */
+ * iteration heat-map (pathtracer.py:419-425) would have shown.  on = 1 counts the reference algorithm's work (every
+ * camera ray walked, as the reference and the oracle do); on = 2 counts what the timed schedule does (the samples fused
+ * into one launch share their camera rays, so a pixel's camera ray is walked -- and counted -- once). */
 int vrt_set_instrumented(vrt_ctx* ctx, int on);
+/* Hash of the sources this library was built from (voxel_rt2_amd/build.py): ties measured counters
+ * (profiles/traffic.json) to the build they were measured on. */
+const char* vrt_build_id(void);
 /* Evaluate one vrt_detmath.h operation on the device (numeric-contract test hook):
  * op 0 sin 1 cos 2 exp 3 log 4 pow 5 acos 6 atan2 7 min 8 max 9 f16 round trip 10 a/b 11 sqrt
  * 12 a*b+a (uncontracted) 13 float->int. */

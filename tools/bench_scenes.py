@@ -23,6 +23,10 @@ CASES = [
     dict(name="sunlit_restir_1080p_d8", scene="sunlit", W=1920, H=1080, depth=8, spp=4, steps=5, restir=True),
     dict(name="s6_nosky_restir_1080p_d8", scene="s6", W=1920, H=1080, depth=8, spp=4, steps=5, restir=True),
     dict(name="s6_nosky_plain_1080p_d8", scene="s6", W=1920, H=1080, depth=8, spp=4, steps=5),
+    # BASELINE config 5: the 256^3 grid (one GPU's form: the whole 4K frame, 4 fused samples per step)
+    dict(name="config5_dense256_4k_d8_1gpu", scene="dense256", W=3840, H=2160, depth=8, spp=4, steps=4, grid=256),
+    dict(name="sponge256_4k_d8", scene="sponge256", W=3840, H=2160, depth=8, spp=4, steps=4, grid=256),
+    dict(name="s1_256_1080p_d8", scene="s1_256", W=1920, H=1080, depth=8, spp=4, steps=10, grid=256),
     # one rank's share of an 8- and a 2-GPU run of config 2 (rows through the middle of the picture)
     dict(name="shard_1of8_config2", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=20, rows=(472, 607)),
     dict(name="shard_1of2_config2", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=20, rows=(0, 540)),
@@ -36,7 +40,7 @@ def run(case):
     if not sky_res:
         params = dict(params, use_physical_sky=0, use_clouds=0)
     cfg = host.make_config(case["W"], case["H"], voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=case["depth"],
-                           seed=0, use_restir=case.get("restir", False), sky_res=sky_res, rows=case.get("rows"))
+                           seed=0, use_restir=case.get("restir", False), sky_res=sky_res, rows=case.get("rows"), grid_res=case.get("grid", 128))
     s = NativeSession(lib, "vrt_", cfg)
     s.upload_voxels(mat, rgb)
     s.upload_materials(materials.load_table())

@@ -41,11 +41,11 @@ class VrtStats(C.Structure):
         ("occupancy_queries", C.c_uint64), ("closest_hits", C.c_uint64), ("sky_lookups", C.c_uint64),
         ("render_ms", C.c_double), ("temporal_ms", C.c_double), ("gris_ms", C.c_double),
         ("render_launches", C.c_uint32), ("temporal_launches", C.c_uint32), ("gris_launches", C.c_uint32),
-        ("pad", C.c_uint32),
+        ("pipeline_flags", C.c_uint32),
     ]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 def declare(lib, prefix):
@@ -75,6 +75,7 @@ def declare(lib, prefix):
     sig("fetch_hdr_device", C.c_int, P, P)
     sig("fetch_hdr_device_async", C.c_int, P, P)
     sig("set_stream", C.c_int, P, P)
+    sig("reserve_cus", C.c_int, P, C.c_int)
     sig("fetch_ldr", C.c_int, P, P)
     sig("fetch_buffer", C.c_int, P, C.c_int, P)
     sig("sync", C.c_int, P)

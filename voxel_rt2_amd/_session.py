@@ -114,6 +114,11 @@ class NativeSession:
     def fetch_hdr_device_async(self, device_ptr):
         self._call("fetch_hdr_device_async", C.c_void_p(int(device_ptr)))
 
+    def reserve_cus(self, n_cus):
+        """Leave n_cus CUs' worth of workgroup slots out of the persistent render grid (multi-GPU: room for RCCL's kernels)."""
+        if getattr(self._lib, self._p + "reserve_cus", None) is not None:
+            self._call("reserve_cus", int(n_cus))
+
     def set_stream(self, hip_stream):
         self._call("set_stream", C.c_void_p(int(hip_stream) if hip_stream else None))
 

@@ -45,10 +45,24 @@ def is_stale():
     return any(os.path.getmtime(p) > t for p in _deps())
 
 
+def source_id():
+    """sha256 (first 16 hex digits) over the sources and flags the library is built from: vrt_build_id()."""
+    import hashlib
+    h = hashlib.sha256()
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip")))
+    files += sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False, extra_flags=()):
     if not force and not is_stale():
         return OUT
-    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [f'-DVRT_BUILD_ID="{source_id()}"'] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

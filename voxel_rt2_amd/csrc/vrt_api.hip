@@ -8,8 +8,10 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/vrt_api.h"
 #include "vrt_kernels.h"
@@ -35,10 +37,12 @@ struct vrt_ctx {
     vrt_camera cam;
     bool have_scene = false, have_cam = false, prepared = false, have_prev = false;
     bool instrumented = false;
+    bool count_as_timed = false;      // instrumented launches keep the camera-ray reuse of the timed schedule (vrt_set_instrumented(ctx, 2))
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = true;
     int n_cu = 0, render_blocks = 0;
+    int reserved_cus = 0;             // CUs' worth of workgroup slots the persistent render grid leaves free (vrt_reserve_cus)
     bool pooled = false;              // render through k_render_pool (vrt_pool.h) instead of k_render
     uint32_t* d_pool_scratch = nullptr;
     PrimaryRecord* d_prim_cache[2] = {nullptr, nullptr};  // camera-ray records of fused launches (one table per render stream)
@@ -86,10 +90,17 @@ struct vrt_ctx {
     uint32_t* alt_pool_scratch = nullptr;  // the second render stream's scratch
     // A render launch queued behind another on the other render stream would be dispatched at once and sit in the
     // queue until workgroups retire -- which the profiler and the events count as its run time.  Instead the kernel
-    // raises this word (HSA signal memory) to launch_seq + 1 when it starts to drain, and the next launch's stream
-    // waits for that value (hipStreamWaitValue32) before the dispatch.
+    // raises this word (HSA signal memory, host visible) to launch_seq + 1 when it starts to drain, and the next
+    // launch's stream waits for that value (hipStreamWaitValue32) before the dispatch.  The gate only TIMES dispatches
+    // (ordering is by events), so raising the word early is always safe: release_gate() does it from the host on
+    // error paths and when a synchronisation overstays (gate_watchdog_ms).  A stream wait is itself a queue operation:
+    // under a tool that runs one queue operation at a time (rocprofv3 --pmc) a wait that is dispatched ahead of the
+    // launch it waits for blocks that launch for ever (tools/probes/probe_gate.cpp reproduces it: the wait completes
+    // by itself in 0.3 ms, never under --pmc, and a host store releases it) -- ensure_overlap() tests for exactly
+    // that once and leaves the gate out where the test fails.
     uint32_t* drain_signal = nullptr;
     bool drain_signalled = false;  // the most recent render launch was given the signal
+    unsigned gate_releases = 0;    // host releases so far (error paths, watchdog): diagnostic
     hipStream_t rstream[2] = {nullptr, nullptr};
     hipEvent_t ev_r[3] = {nullptr, nullptr, nullptr}, ev_t[3] = {nullptr, nullptr, nullptr}, ev_main = nullptr;
     bool ev_t_valid[3] = {false, false, false};
@@ -111,6 +122,54 @@ static hipError_t dalloc(T** p, size_t n) {
     hipError_t e = hipMalloc((void**)p, n * sizeof(T));
     if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(T));
     return e;
+}
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Host store to the gate word: every launch queued so far counts as draining.  launch_seq is at least what any launch in
+// flight will raise the word to, and later launches raise it further (atomic max), so no wait can be lost.
+static void release_gate(vrt_ctx* c) {
+    if (!c->drain_signal) return;
+    __atomic_store_n(c->drain_signal, (uint32_t)c->launch_seq, __ATOMIC_RELEASE);
+    c->gate_releases++;
+}
+
+// hipStreamSynchronize with a bound on how long a gated launch may hold the stream: past it the gate is released from
+// the host (harmless when the launches are merely long; the way out when a dispatch never comes).
+static hipError_t sync_guarded(vrt_ctx* c, hipStream_t st) {
+    if (c->drain_signal && c->drain_signalled) {
+        double limit = 2.0;
+        if (const char* e = getenv("VRT_GATE_WATCHDOG_MS")) { const double v = atof(e); if (v > 0.0) limit = v * 1e-3; }
+        const double t0 = now_s();
+        for (int polls = 0;; polls++) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
+            if (now_s() - t0 > limit) { release_gate(c); break; }
+            if (polls > 64) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
+    return hipStreamSynchronize(st);
+}
+
+// True when a stream wait queued BEFORE the operation that satisfies it (on the other render stream) completes: the
+// order in which a launch and the wait of its successor can reach the hardware.  Under a tool that serialises queue
+// operations it does not -- then the word is released from the host and the caller leaves the gate out.
+static bool gate_self_test(vrt_ctx* c) {
+    if (hipStreamWaitValue32(c->rstream[1], c->drain_signal, 1u, hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess) { (void)hipGetLastError(); return false; }
+    bool wrote = hipStreamWriteValue32(c->rstream[0], c->drain_signal, 1u, 0) == hipSuccess;
+    bool by_itself = false;
+    const double t0 = now_s();
+    while (wrote && now_s() - t0 < 0.1) {
+        if (hipStreamQuery(c->rstream[1]) == hipSuccess) { by_itself = true; break; }
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    (void)hipGetLastError();
+    if (!by_itself) __atomic_store_n(c->drain_signal, 1u, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(c->rstream[1]);
+    (void)hipStreamSynchronize(c->rstream[0]);
+    __atomic_store_n(c->drain_signal, 0u, __ATOMIC_RELEASE);
+    (void)hipGetLastError();
+    return by_itself;
 }
 
 static void resolve_events(vrt_ctx* c) {
@@ -194,6 +253,10 @@ static void sun_of(const vrt_ctx* c, f3& dir, f3& col, float& cosm) {
 extern "C" {
 
 const char* vrt_last_error(void) { return g_err.c_str(); }
+#ifndef VRT_BUILD_ID
+#define VRT_BUILD_ID "unknown"
+#endif
+const char* vrt_build_id(void) { return VRT_BUILD_ID; }
 
 vrt_ctx* vrt_create(const vrt_config* cfg) {
     if (!cfg) { fail(VRT_E_INVALID, "null config"); return nullptr; }
@@ -276,6 +339,7 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
 void vrt_destroy(vrt_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    release_gate(c);   // nothing may be left waiting at a gate
     for (int s = 0; s < 2; s++) if (c->rstream[s]) hipStreamSynchronize(c->rstream[s]);
     if (c->stream) hipStreamSynchronize(c->stream);
     resolve_events(c);
@@ -306,7 +370,7 @@ int vrt_upload_voxels(vrt_ctx* c, const int8_t* mat, const uint8_t* rgb) {
     const size_t nvox = (size_t)c->cfg.grid_res * c->cfg.grid_res * c->cfg.grid_res;
     HIP_TRY(hipMemcpyAsync(c->d_mat, mat, nvox, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_rgb, rgb, nvox * 3, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // host buffers are only borrowed for the call
+    HIP_TRY(sync_guarded(c, c->stream));  // host buffers are only borrowed for the call
     c->prepared = false;
     return VRT_OK;
 }
@@ -315,7 +379,7 @@ int vrt_upload_materials(vrt_ctx* c, const float* table) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->d_mats, table, 128 * 14 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_mat_derived(c->stream, c->d_mats, c->d_mats_x));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_guarded(c, c->stream));
     return VRT_OK;
 }
 int vrt_upload_cloud_texture(vrt_ctx* c, const uint8_t* rgb) {
@@ -323,7 +387,7 @@ int vrt_upload_cloud_texture(vrt_ctx* c, const uint8_t* rgb) {
     if (c->cfg.sky_res <= 0) return fail(VRT_E_STATE, "context was created without sky tables (sky_res = 0)");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->d_cloud_tex, rgb, 256 * 256 * 3, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_guarded(c, c->stream));
     return VRT_OK;
 }
 int vrt_set_scene(vrt_ctx* c, const vrt_scene_params* s) {
@@ -342,9 +406,17 @@ int vrt_set_camera(vrt_ctx* c, const vrt_camera* cam) {
     c->have_cam = true;
     return VRT_OK;
 }
+int vrt_reserve_cus(vrt_ctx* c, int n_cus) {
+    if (!c || n_cus < 0) return fail(VRT_E_INVALID, "bad argument");
+    if (n_cus > c->n_cu - 8) n_cus = c->n_cu - 8 > 0 ? c->n_cu - 8 : 0;
+    c->reserved_cus = n_cus;
+    c->render_blocks = 0;   // the grid is sized again at the next vrt_accumulate
+    return VRT_OK;
+}
 int vrt_set_instrumented(vrt_ctx* c, int on) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     c->instrumented = on != 0;
+    c->count_as_timed = on == 2;
     c->render_blocks = 0;
     return VRT_OK;
 }
@@ -416,24 +488,52 @@ static bool ensure_overlap(vrt_ctx* c) {
              hipEventCreateWithFlags(&c->ev_t[s], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) == hipSuccess;
     int can_wait = 0;
-    if (ok && hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, c->device) == hipSuccess && can_wait &&
+    bool want_gate = ok;
+    if (const char* e = getenv("VRT_DRAIN_GATE")) want_gate = want_gate && atoi(e) != 0;   // 0: launches overlap all the same, only queue earlier
+    c->drain_signal = nullptr;
+    if (want_gate && hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, c->device) == hipSuccess && can_wait &&
         hipExtMallocWithFlags((void**)&c->drain_signal, 8, hipMallocSignalMemory) == hipSuccess) {
-        if (hipStreamWriteValue32(c->stream, c->drain_signal, 0u, 0) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
-            (void)hipGetLastError(); hipFree(c->drain_signal); c->drain_signal = nullptr;
-        }
-    } else {
-        (void)hipGetLastError(); c->drain_signal = nullptr;  // no stream wait: launches overlap all the same, only queue earlier
+        hipPointerAttribute_t at;
+        bool usable = hipPointerGetAttributes(&at, c->drain_signal) == hipSuccess && at.hostPointer == (void*)c->drain_signal;  // the host must be able to release it
+        if (usable) { __atomic_store_n(c->drain_signal, 0u, __ATOMIC_RELEASE); usable = gate_self_test(c); }
+        if (!usable) { (void)hipGetLastError(); hipFree(c->drain_signal); c->drain_signal = nullptr; }
     }
+    (void)hipGetLastError();
     if (!ok) { (void)hipGetLastError(); c->overlap_failed = true; return false; }
     c->overlap_ready = true;
     return true;
 }
+
+// After a failed queue operation inside vrt_accumulate: nothing may be left waiting for a launch that did not happen, and
+// the context must be usable again.  The rotation state (buffer roles, frame index, pipeline slot) only advances at the end
+// of an iteration whose launches were all queued, so the context is back at the pass before the failed one.
+static void abort_pipeline(vrt_ctx* c) {
+    const std::string keep = g_err;
+    release_gate(c);
+    c->drain_signalled = false;
+    for (int s = 0; s < 2; s++) if (c->rstream[s]) (void)hipStreamSynchronize(c->rstream[s]);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipGetLastError();
+    resolve_events(c);
+    c->ev_t_valid[0] = c->ev_t_valid[1] = c->ev_t_valid[2] = false;
+    c->main_dirty = true;
+    c->render_blocks = 0;   // residency and scratch are looked at again
+    g_err = keep;
+}
+
+static int accumulate_impl(vrt_ctx* c, int n_samples);
 
 int vrt_accumulate(vrt_ctx* c, int n_samples) {
     if (!c || n_samples < 0) return fail(VRT_E_INVALID, "bad argument");
     if (!c->prepared) return fail(VRT_E_STATE, "vrt_prepare has not run since the last voxel upload");
     if (!c->have_cam) return fail(VRT_E_STATE, "vrt_set_camera has not been called");
     HIP_TRY(hipSetDevice(c->device));
+    const int rc = accumulate_impl(c, n_samples);
+    if (rc != VRT_OK) abort_pipeline(c);
+    return rc;
+}
+
+static int accumulate_impl(vrt_ctx* c, int n_samples) {
     const bool restir = c->cfg.use_restir != 0, instr = c->instrumented;
     if (c->render_blocks == 0) {
         // Two schedules of the same per-path code: the fused one (a lane owns a path, vrt_path.h) and the pooled one
@@ -450,14 +550,16 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         else HIP_TRY(query_render_residency(c->cfg.grid_res, restir, instr, &per_cu));
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
-        c->render_blocks = per_cu * c->n_cu;
+        int cus = c->n_cu - c->reserved_cus;
+        if (cus < 8) cus = c->n_cu < 8 ? c->n_cu : 8;
+        c->render_blocks = per_cu * cus;   // (abort_pipeline zeroes it again if an allocation below fails)
         c->pooled = pooled;
         if (pooled) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(sync_guarded(c, c->stream));
             if (c->d_pool_scratch) { HIP_TRY(hipFree(c->d_pool_scratch)); c->d_pool_scratch = nullptr; }
             HIP_TRY(hipMalloc((void**)&c->d_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->render_blocks)));
-            if (c->alt_pool_scratch) {
-                HIP_TRY(hipFree(c->alt_pool_scratch)); c->alt_pool_scratch = nullptr;
+            if (c->overlap_ready) {  // the second render stream's scratch follows
+                if (c->alt_pool_scratch) { HIP_TRY(hipFree(c->alt_pool_scratch)); c->alt_pool_scratch = nullptr; }
                 HIP_TRY(hipMalloc((void**)&c->alt_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->render_blocks)));
             }
         }
@@ -477,9 +579,6 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
     // run beside them.  Results are unchanged; VRT_OVERLAP=0 turns it off.
     bool may_overlap = c->pooled && can_fuse;
     if (const char* e = getenv("VRT_OVERLAP")) { if (atoi(e) == 0) may_overlap = false; }
-    // rocprofv3 --pmc runs one kernel at a time through an intercepted queue, on which the stream-wait packet never
-    // completes (observed: every counter pass hung); counters are per kernel and want isolated launches anyway
-    if (const char* e = getenv("ROCPROF_COUNTER_COLLECTION")) { if (atoi(e) != 0) may_overlap = false; }
     for (int done = 0; done < n_samples;) {
         int g = (can_fuse && n_samples - done > 1) ? (n_samples - done < max_fused ? n_samples - done : max_fused) : 1;
         if (g > 1 && !c->d_multi_d) {
@@ -538,7 +637,7 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
         HIP_TRY(hipEventRecord(a, rs));
         const unsigned seq = c->launch_seq++;
         PrimaryRecord* prim = nullptr;  // fused samples share their camera rays through this table (vrt_pool.h)
-        if (c->pooled && g > 1) {
+        if (c->pooled && g > 1 && (!instr || c->count_as_timed)) {  // counting the reference's work: every camera ray is walked
             const int which = (overlapped && lane_of) ? 1 : 0;
             if (!c->d_prim_cache[which] && dalloc(&c->d_prim_cache[which], c->npix) != hipSuccess) { (void)hipGetLastError(); c->d_prim_cache[which] = nullptr; }
             prim = c->d_prim_cache[which];
@@ -620,7 +719,7 @@ int vrt_end_frame(vrt_ctx* c) {
 int vrt_sync(vrt_ctx* c) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // every render launch on the render streams has its temporal pass here
+    HIP_TRY(sync_guarded(c, c->stream));  // every render launch on the render streams has its temporal pass here
     return VRT_OK;
 }
 
@@ -632,7 +731,7 @@ static int fetch_rows(vrt_ctx* c, const void* dbuf, size_t elem, void* out) {
     const char* src = (const char*)dbuf + (size_t)(c->own0 - c->buf0) * W * elem;
     char* dst = (char*)out + (size_t)c->own0 * W * elem;
     HIP_TRY(hipMemcpyAsync(dst, src, (size_t)(c->own1 - c->own0) * W * elem, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_guarded(c, c->stream));
     return VRT_OK;
 }
 int vrt_fetch_hdr(vrt_ctx* c, float* out) {
@@ -645,7 +744,7 @@ int vrt_fetch_hdr_device(vrt_ctx* c, void* device_ptr) {
     const size_t W = c->cfg.width;
     const char* src = (const char*)c->d_cbuf[c->cidx] + (size_t)(c->own0 - c->buf0) * W * sizeof(f3);
     HIP_TRY(hipMemcpyAsync(device_ptr, src, (size_t)(c->own1 - c->own0) * W * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_guarded(c, c->stream));
     return VRT_OK;
 }
 int vrt_fetch_hdr_device_async(vrt_ctx* c, void* device_ptr) {
@@ -659,7 +758,7 @@ int vrt_fetch_hdr_device_async(vrt_ctx* c, void* device_ptr) {
 int vrt_set_stream(vrt_ctx* c, void* hip_stream) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_guarded(c, c->stream));
     resolve_events(c);
     c->ev_t_valid[0] = c->ev_t_valid[1] = c->ev_t_valid[2] = false;  // everything recorded on the old stream has completed
     c->main_dirty = true;
@@ -694,13 +793,13 @@ int vrt_fetch_buffer(vrt_ctx* c, int which, void* out) {
         if (c->cfg.sky_res <= 0) return fail(VRT_E_STATE, "no sky tables");
         size_t ns = (size_t)c->cfg.sky_res * c->cfg.sky_res * 3 * sizeof(float);
         HIP_TRY(hipMemcpyAsync(out, which == VRT_BUF_SKY_SCATTERING ? c->d_sky_scat : c->d_sky_trans, ns, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(sync_guarded(c, c->stream));
         return VRT_OK;
     }
     if (which == VRT_BUF_TRANS_LUT) {
         if (c->cfg.sky_res <= 0) return fail(VRT_E_STATE, "no sky tables");
         HIP_TRY(hipMemcpyAsync(out, c->d_trans_lut, 256 * 128 * 3 * 2, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(sync_guarded(c, c->stream));
         return VRT_OK;
     }
     return fail(VRT_E_INVALID, "unknown buffer id");
@@ -708,19 +807,20 @@ int vrt_fetch_buffer(vrt_ctx* c, int which, void* out) {
 int vrt_get_stats(vrt_ctx* c, vrt_stats* out) {
     if (!c || !out) return fail(VRT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_guarded(c, c->stream));
     resolve_events(c);
     Counters h;
     HIP_TRY(hipMemcpy(&h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     c->stats.rays = h.rays; c->stats.dda_iters = h.iters; c->stats.occupancy_queries = h.queries;
     c->stats.closest_hits = h.closest_hits; c->stats.sky_lookups = h.sky_lookups;
+    c->stats.pipeline_flags = (c->overlap_ready ? 1u : 0u) | (c->drain_signal ? 2u : 0u) | ((uint32_t)c->gate_releases << 8);
     *out = c->stats;
     return VRT_OK;
 }
 int vrt_reset_stats(vrt_ctx* c) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_guarded(c, c->stream));
     resolve_events(c);
     HIP_TRY(hipMemset(c->d_counters, 0, sizeof(Counters)));
     memset(&c->stats, 0, sizeof(c->stats));
@@ -734,7 +834,7 @@ int vrt_diag_regions(vrt_ctx* c, unsigned long long* out64, int reset) {
     HIP_TRY(hipMalloc((void**)&d, 64 * sizeof(unsigned long long)));
     hipError_t e = launch_diag_read(c->stream, d, reset);
     if (e != hipSuccess) { hipFree(d); return fail(VRT_E_STATE, "library was not built with VRT_DIAG_REGIONS"); }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_guarded(c, c->stream));
     HIP_TRY(hipMemcpy(out64, d, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     hipFree(d);
     return VRT_OK;

@@ -417,12 +417,12 @@ __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attr
                     VRT_REGION(16);
                     walk_store(s, w);
                     state[slot] = (uint32_t)slot_state_after_walk<G>(w.t, s.f(PF_FLOOR_T));
-                    if (!INSTR && prim_cache) {  // the camera ray of a pixel's sample 0: leave its record for the other samples
+                    if (prim_cache) {  // the camera ray of a pixel's sample 0: leave its record for the other samples
                         const uint32_t ids = s.u(PF_IDS);
                         if ((ids >> 24) == 0u) {  // depth 0, sample 0
                             typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                             const PrimaryRecord r = primary_record(s, prim_tag);
-                            const u32x4 r4 = {r.x, r.y, r.z, r.w};  // ONE 16-byte store: a reader sees the tag with its record or neither
+                            const u32x4 r4 = {r.x, r.y, r.z, r.w};  // one 16-byte store; the check word tells a reader whether it saw all of it
                             *(u32x4*)&prim_cache[((int)((ids >> 12) & 0xfffu) - fp.row0) * fp.W + (int)(ids & 0xfffu)] = r4;
                         }
                     }
@@ -515,11 +515,11 @@ __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attr
                             bool known = false;
                             PrimaryRecord rec;
                             rec.x = rec.y = rec.z = rec.w = 0u;
-                            if (!INSTR && prim_cache && sample > 0) {
+                            if (prim_cache && sample > 0) {
                                 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                                 const u32x4 r4 = __builtin_nontemporal_load((const u32x4*)&prim_cache[(v - fp.row0) * fp.W + u]);  // one 16-byte load past L1: another CU wrote it
                                 rec.x = r4.x; rec.y = r4.y; rec.z = r4.z; rec.w = r4.w;
-                                known = rec.w == prim_tag;
+                                known = primary_record_valid(rec, prim_tag);
                             }
                             state[slot] = (uint32_t)(known ? pool_begin_known<G>(fp, s, u, v, sample, rec) : pool_begin<G>(fp, s, u, v, sample, ts));
                         }

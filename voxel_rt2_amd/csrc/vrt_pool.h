@@ -179,13 +179,26 @@ VRT_DEV int pool_launch_ray(const FrameParams& fp, const SlotRef& s, f3 pos, f3 
 // leaves the record (distance, cell, normal code; tagged with the launch) in a per-pixel table when its walk ends;
 // work items are ordered sample-major within a work range, so by the time a pixel's later samples begin, the
 // record is there and they start at SHADE / ESCAPE without setting up or walking a ray.  A missing or stale record
-// (other tag) just means the ray is walked as usual.  Records are written and read as one 16-byte word.
-struct alignas(16) PrimaryRecord { uint32_t x, y, z, w; };  // PF_T, PF_CELL_XY, PF_CELL_Z, launch tag
+// just means the ray is walked as usual.  Writer and reader are different CUs with no fence between them (a release /
+// acquire pair costs microseconds, MI355X_MICROARCH.md: this is per ray), so nothing is ASSUMED about how the 16 bytes
+// arrive: the fourth word is the launch tag mixed with a hash of the three payload words, and a reader accepts a record
+// only if that word matches the payload it read and the launch it runs in.  A stale record (other launch), a missing one
+// and a torn one -- words of two different stores -- all fail the check (a tear passes with probability 2^-32) and the
+// ray is walked.  The record is still written and read with one 16-byte instruction each (observed untorn on gfx950).
+struct alignas(16) PrimaryRecord { uint32_t x, y, z, w; };  // PF_T, PF_CELL_XY, PF_CELL_Z, check word
+VRT_DEV uint32_t primary_check(uint32_t x, uint32_t y, uint32_t z, uint32_t tag) {
+    uint32_t h = x * 0x9E3779B1u;
+    h = (h ^ (h >> 15)) + y * 0x85EBCA77u;
+    h = (h ^ (h >> 13)) + z * 0xC2B2AE3Du;
+    h ^= h >> 16;
+    return h ^ tag;
+}
 VRT_DEV PrimaryRecord primary_record(const SlotRef& s, uint32_t tag) {
     PrimaryRecord r;
-    r.x = s.u(PF_T); r.y = s.u(PF_CELL_XY); r.z = s.u(PF_CELL_Z); r.w = tag;
+    r.x = s.u(PF_T); r.y = s.u(PF_CELL_XY); r.z = s.u(PF_CELL_Z); r.w = primary_check(r.x, r.y, r.z, tag);
     return r;
 }
+VRT_DEV bool primary_record_valid(const PrimaryRecord& r, uint32_t tag) { return r.w == primary_check(r.x, r.y, r.z, tag); }
 template <int G>
 VRT_DEV int pool_begin_known(const FrameParams& fp, const SlotRef& s, int u, int v, int sample, PrimaryRecord rec) {
     Path<false> p;

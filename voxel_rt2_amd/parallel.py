@@ -6,7 +6,25 @@ streams, so a rank renders its contiguous rows (plus a small halo it renders red
 data-path communication; the only exchange is one gather of the finished tiles per presented frame:
 at 1080p each of 7 peers sends 135 x 1920 x 12 B = 3.1 MB straight to rank 0 over its own xGMI link.
 """
+import os
+
 import numpy as np
+
+# CUs' worth of workgroup slots a rank's persistent render grid leaves free when the process group has more than one rank,
+# so that RCCL's gather kernel can be scheduled while a render launch is resident (include/vrt_api.h: vrt_reserve_cus).
+# One GPU's cost of the reservation on config 2: DESIGN.md section 8.
+DEFAULT_RESERVED_CUS = 8
+
+
+def reserved_cus(world_size):
+    if world_size <= 1:
+        return 0
+    return int(os.environ.get("VRT_RESERVE_CUS", DEFAULT_RESERVED_CUS))
+
+
+def configure_session(sess, world_size):
+    """What a rank's render context needs beyond a single-GPU one."""
+    sess.reserve_cus(reserved_cus(world_size))
 
 
 def split_rows(height, world_size):
