@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: Mpath-samples/s of Renderer.accumulate() on MI355X.
 
-Workload (BASELINE.json configs[1]): example-1-style scene S1 on the 128^3 grid, 1920x1080,
+Headline workload (BASELINE.json configs[1]): example-1-style scene S1 on the 128^3 grid, 1920x1080,
 4 spp per frame, 8 bounces.  One "step" = one frame = 4 accumulate() passes over every pixel;
 a path-sample = one pixel x one pass.  All inputs are resident in HBM
 before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-secondary] [--no-cpu-baseline]
 
 N > 1 is launched by the driver through torch.distributed.run, one rank per GPU: the frame is
 split into N contiguous row tiles (strong scaling: the frame is fixed), every rank renders its
 tile with no data-path communication, and the HDR tiles are gathered to rank 0 over RCCL at the
 end of every step (inside the timed region).
 
-Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel (k_render_pool)
-and the CPU-oracle baseline timed on this box's host cores.
+Rank 0 prints ONE JSON line: the headline throughput, the roofline of its dominant kernel
+(k_render_pool), the CPU-oracle baseline timed on this box's host cores and -- on one GPU -- a
+`secondary` list with the other BASELINE configs in their one-GPU form (config 3: sky + clouds +
+ReSTIR at 1080p; config 4: dense 128^3 at 3840x2160; config 5: dense 256^3 at 3840x2160), each
+with its own dominant kernel, duration, algorithmic bytes and roofline fraction.
 """
 import argparse
 import ctypes as C
@@ -30,14 +33,20 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 import numpy as np  # noqa: E402
 
-# The library renders on two streams of its own beside the caller's; a multi-GPU rank adds the gather stream and RCCL's.
-# The HIP runtime multiplexes streams onto 4 hardware queues by default, and two streams that share a queue serialise: a
-# wait queued for the gather then holds back the next render launch (measured on one rank's share of an 8-way split:
-# 0.418 ms per step with 4 queues, 0.317 with 8).  Must be set before the runtime starts.
+# More hardware queues than the HIP runtime's default 4 (voxel_rt2_amd/_lib.py explains; it sets the same default when
+# the library is loaded first).  Must be in the environment before the runtime starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 WIDTH, HEIGHT, SPP_PER_STEP, MAX_DEPTH, SEED = 1920, 1080, 4, 8, 0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# VALU issue: a wave64 vector instruction takes 2 cycles on a SIMD-32 (MI355X_MICROARCH.md:54, 473): 256 CUs x 4 SIMDs x
+# 2.4 GHz / 2.  Measured on this chip with an independent v_fma_f32 stream (tools/probes/valu_issue.cpp,
+# profiles/r02_valu_issue.txt): 836 G wave-instructions/s with 4 waves per SIMD, 778 with the 2 waves per SIMD the
+# render kernels run at (2.75 cycles per instruction; the chip clocks down to 1.7-2.1 GHz under that load).
+VALU_PEAK_NOMINAL, VALU_PEAK_MEASURED_2WAVES = 1228.8, 778.0
+# reference-algorithm bytes of one spatial-reuse pass per pixel: 32 taps x ~75 B of g-buffer and
+# reservoir, 55 B reservoir written, 24 B of colour written
+GRIS_BYTES_PER_PIXEL = 32 * 75 + 55 + 24
 
 
 def split_rows(height, n):
@@ -45,10 +54,12 @@ def split_rows(height, n):
     return [(edges[i], edges[i + 1]) for i in range(n)]
 
 
-def setup_session(sess, mat, rgb, params):
+def setup_session(sess, mat, rgb, params, cloud=None):
     from voxel_rt2_amd import host, materials
     sess.upload_voxels(mat, rgb)
     sess.upload_materials(materials.load_table())
+    if cloud is not None:
+        sess.upload_cloud_texture(cloud)
     sess.set_scene(host.make_scene_params(**params))
     sess.set_camera(host.default_camera(sess.W, sess.H, jitter_index=1))
     sess.prepare()
@@ -56,11 +67,10 @@ def setup_session(sess, mat, rgb, params):
 
 def cpu_baseline(mat, rgb, params):
     """The CPU oracle (oracle/, a restatement of the reference's ti.cpu path) on a bounded sample
-    of the same workload: a central band of rows of the same frame, same depth / spp / seed."""
+    of the same workload: the same frame, depth, spp and seed, a few accumulate passes."""
     import orc
     from voxel_rt2_amd import host
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    rows = (0, HEIGHT)
     cfg = host.make_config(WIDTH, HEIGHT, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=MAX_DEPTH,
                            seed=SEED)
     o = orc.Oracle(cfg, threads=cores)
@@ -74,26 +84,150 @@ def cpu_baseline(mat, rgb, params):
     o.accumulate(passes)
     dt = time.perf_counter() - t0
     samples = WIDTH * HEIGHT * passes
-    hdr = o.fetch_hdr()
     o.close()
     return dict(value=samples / dt / 1e6, unit="Mpath-samples/s", cores=cores, kind="port",
                 sample=f"the whole {WIDTH}x{HEIGHT} frame, {passes} accumulate passes, {MAX_DEPTH} bounces, same scene and seed "
                        f"({samples} path-samples in {dt:.1f} s on {cores} threads; oracle/ = CPU restatement of the "
-                       f"reference's ti.cpu path, reported only)"), hdr, rows
+                       f"reference's ti.cpu path, reported only)")
+
+
+def measured_counters(lib):
+    """profiles/traffic.json: HBM bytes and VALU instructions per launch from rocprofv3 --pmc passes -- only if they were
+    taken on the build that is loaded now (vrt_build_id), else nothing."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tfile))
+    except Exception:
+        return {}, None
+    have = lib.vrt_build_id().decode()
+    if tj.get("build_id") != have:
+        return {}, f"profiles/traffic.json was measured on build {tj.get('build_id')}, loaded library is {have}: not reported"
+    return tj.get("kernels", {}), None
+
+
+def count_work(lib, sess, spp):
+    """Per path-sample counts from instrumented launches: the reference algorithm's (every camera ray walked, what the
+    oracle counts too) and the timed schedule's own (fused samples share their camera rays)."""
+    out = {}
+    for mode, key in ((1, "reference"), (2, "timed")):
+        lib.vrt_set_instrumented(C.c_void_p(sess._ctx), mode)
+        lib.vrt_reset_stats(C.c_void_p(sess._ctx))
+        sess.accumulate(spp)
+        ist = sess.stats()
+        n = max(ist["path_samples"], 1)
+        out[key] = dict(q=ist["occupancy_queries"] / n, hc=ist["closest_hits"] / n, ls=ist["sky_lookups"] / n,
+                        rays=ist["rays"] / n, iters=ist["dda_iters"] / n)
+    lib.vrt_set_instrumented(C.c_void_p(sess._ctx), 0)
+    return out
+
+
+def render_bytes(c):
+    # SURVEY.md section 8d, render-kernel share: 4 B per occupancy query + (4 B texel + 56 B material row) per closest hit
+    # + 96 B per sky lookup + 52 B written per path (two colour values and the g-buffer)
+    return 4.0 * c["q"] + 60.0 * c["hc"] + 96.0 * c["ls"] + 52.0
+
+
+def roofline_block(kernel, kernel_ms, units_per_launch, bytes_ref, bytes_timed, counters, notes):
+    """HBM roofline of one kernel: algorithmic bytes per launch over its measured duration."""
+    ach = bytes_timed * units_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    ach_ref = bytes_ref * units_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    k = counters.get(kernel, {}) if counters else {}
+    traffic = k.get("bytes_per_launch")
+    valu = k.get("valu_wave_insts_per_launch")
+    blk = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic,
+           "algorithmic_bytes_per_unit": round(bytes_timed, 2),
+           "reference_algorithm": {"bytes_per_unit": round(bytes_ref, 2), "achieved": round(ach_ref, 3), "frac": round(ach_ref / HBM_PEAK_GBS, 6)},
+           "units_per_launch": int(units_per_launch), "kernel_ms_per_launch": round(kernel_ms, 4)}
+    if traffic and kernel_ms > 0:
+        blk["traffic_GBps"] = round(traffic / (kernel_ms * 1e-3) / 1e9, 1)
+        blk["traffic_frac"] = round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+    if valu and kernel_ms > 0:
+        g = valu / (kernel_ms * 1e-3) / 1e9
+        blk["valu_issue"] = {"achieved": round(g, 1), "unit": "G wave-instructions/s", "peak_nominal": VALU_PEAK_NOMINAL,
+                             "frac_nominal": round(g / VALU_PEAK_NOMINAL, 4), "peak_measured_2_waves_per_simd": VALU_PEAK_MEASURED_2WAVES,
+                             "frac_measured": round(g / VALU_PEAK_MEASURED_2WAVES, 4)}
+    blk["note"] = notes
+    return blk
+
+
+SECONDARY = [
+    dict(config="3", name="config3_s6_sky_clouds_restir_1080p", scene="s6", W=1920, H=1080, depth=8, spp=4, steps=8, restir=True, sky_res=3840,
+         workload="example6-style scene S6 (scenes.scene_s6), physical sky + clouds (3840^2 tables precomputed untimed), ReSTIR spatial reuse on, "
+                  "128^3 grid, 1920x1080, 4 spp/step, 8 bounces"),
+    dict(config="4 (one GPU's form)", name="config4_dense_4k", scene="dense", W=3840, H=2160, depth=8, spp=4, steps=8,
+         workload="dense random 128^3 fill (p = 0.5, seed 12345), 3840x2160, 4 spp/step (16 spp = 4 steps), 8 bounces, the whole frame on one GPU"),
+    dict(config="5 (one GPU's form)", name="config5_dense256_4k", scene="dense256", W=3840, H=2160, depth=8, spp=4, steps=8, grid=256,
+         workload="dense random 256^3 fill (p = 0.5, seed 12345; 64 MiB of texels, 2 MiB of fine brick words), 3840x2160, 4 spp/step "
+                  "(32 spp = 8 steps), 8 bounces, the whole frame on one GPU"),
+]
+
+
+def run_secondary(lib, case, counters):
+    from voxel_rt2_amd import host, scenes
+    from voxel_rt2_amd._session import NativeSession
+    mat, rgb, params = scenes.SCENES[case["scene"]](12345 if case["scene"].startswith("dense") else 0)
+    sky_res = case.get("sky_res", 0)
+    if not sky_res:
+        params = dict(params, use_physical_sky=0, use_clouds=0)
+    cfg = host.make_config(case["W"], case["H"], voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=case["depth"],
+                           seed=SEED, use_restir=case.get("restir", False), sky_res=sky_res, grid_res=case.get("grid", 128))
+    s = NativeSession(lib, "vrt_", cfg)
+    cloud = np.load(os.path.join(ROOT, "voxel_rt2_amd", "data", "cloud_texture.npy")) if sky_res else None
+    setup_session(s, mat, rgb, params, cloud)
+    if sky_res:  # Scene.finish()'s precompute (scene.py:243-253), untimed
+        for _ in range(32):
+            s.sky_accumulate_clouds(32)
+        for sl in range(32):
+            s.sky_compute_slice(sl, 32)
+    spp, steps = case["spp"], case["steps"]
+    for _ in range(4):   # set-up of the overlapped pipeline + warm-up
+        s.accumulate(spp)
+    s.sync()
+    lib.vrt_reset_stats(C.c_void_p(s._ctx))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s.accumulate(spp)
+    s.sync()
+    dt = time.perf_counter() - t0
+    st = s.stats()
+    work = count_work(lib, s, spp)
+    hdr_ok = bool(np.isfinite(s.fetch_hdr()).all())
+    s.close()
+    px = case["W"] * case["H"]
+    ms = {k: st[f"{k}_ms"] / max(st[f"{k}_launches"], 1) for k in ("render", "gris", "temporal")}
+    per_launch = st["path_samples"] / max(st["render_launches"], 1)
+    if case.get("restir"):
+        # per sample: k_render<restir> + k_gris_prepare + k_gris + k_temporal; the spatial-reuse pass dominates
+        kernel, kms, units = "k_gris", ms["gris"], px
+        b_ref = b_timed = float(GRIS_BYTES_PER_PIXEL)
+        note = ("dominant kernel of this config: the ReSTIR spatial-reuse pass (k_gris_prepare + k_gris, timed together); unit = one pixel of "
+                "one pass; bytes = the reference algorithm's reads/writes per pixel (SURVEY.md 8 a13); the pass is VALU bound (DESIGN.md 4)")
+    else:
+        kernel, kms, units = "k_render_pool", ms["render"], per_launch
+        b_ref, b_timed = render_bytes(work["reference"]), render_bytes(work["timed"])
+        note = "unit = one path-sample; launches overlap, so the kernel duration is a launch's span and the step period is ms_per_step"
+    return {"config": case["config"], "name": case["name"], "workload": case["workload"], "metric": "Mpath-samples/sec", "value": round(px * spp * steps / dt / 1e6, 2),
+            "unit": "Mpath-samples/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "finite": hdr_ok,
+            "kernel_ms_per_launch": {k: round(v, 4) for k, v in ms.items()},
+            "work_per_path_sample": {k: {a: round(b, 3) for a, b in v.items()} for k, v in work.items()},
+            "roofline": roofline_block(kernel, kms, units, b_ref, b_timed, counters.get(case["name"], {}), note)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)   # SURVEY.md 8d: at least 50 timed frames
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
+    from voxel_rt2_amd import host, scenes, _lib, parallel
+    from voxel_rt2_amd._session import NativeSession
+    lib = _lib.load()   # before torch touches the device: the library picks the HIP runtime torch ships (and the queue count)
     import torch
     import torch.distributed as dist
-    from voxel_rt2_amd import host, scenes, _lib
-    from voxel_rt2_amd._session import NativeSession
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -119,9 +253,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     coll_dev = "cpu" if rehearse else "cuda"
 
-    from voxel_rt2_amd import parallel
     mat, rgb, params = scenes.scene_s1(0)
-    lib = _lib.load()
     stream = torch.cuda.Stream()  # the context's stream: temporal passes and the tile copy (render launches go to the library's own streams)
 
     def make_session(rows):
@@ -129,6 +261,7 @@ def main():
                                seed=SEED, device=local_rank, rows=rows if world > 1 else None)
         s = NativeSession(lib, "vrt_", cfg)
         s.set_stream(stream.cuda_stream)
+        parallel.configure_session(s, world)   # N > 1: leave workgroup slots free for RCCL's kernels
         setup_session(s, mat, rgb, params)
         return s
 
@@ -234,71 +367,57 @@ def main():
         if not same:
             raise SystemExit("rehearsal: gathered frame differs from the unsharded render")
 
-    # algorithmic bytes of the dominant kernel: one untimed instrumented pass counts what a path does
-    lib.vrt_set_instrumented(C.c_void_p(sess._ctx), 1)
-    lib.vrt_reset_stats(C.c_void_p(sess._ctx))
-    sess.accumulate(SPP_PER_STEP)
-    ist = sess.stats()
-    lib.vrt_set_instrumented(C.c_void_p(sess._ctx), 0)
+    # what a path-sample of this rank's tile does: untimed instrumented launches
+    work = count_work(lib, sess, SPP_PER_STEP)
+    sess.sync()
 
     if rank == 0:
         total_samples = WIDTH * HEIGHT * SPP_PER_STEP * args.steps
         value = total_samples / elapsed / 1e6
-        own_px = WIDTH * (rows[1] - rows[0])
-        # per path-sample counts on this rank's tile (SURVEY.md section 8d formula, render-kernel share):
-        # 4 B per occupancy query + (4 B texel + 56 B material row) per closest hit + 96 B per sky lookup
-        # + 52 B written per path (two colour values and the g-buffer)
-        n_inst = max(ist["path_samples"], 1)
-        q, hc, ls = ist["occupancy_queries"] / n_inst, ist["closest_hits"] / n_inst, ist["sky_lookups"] / n_inst
-        bytes_per_sample = 4.0 * q + 60.0 * hc + 96.0 * ls + 52.0
         launches = max(st["render_launches"], 1)
         avg_ms = st["render_ms"] / launches
-        samples_per_launch = st["path_samples"] / launches  # a launch renders own_px pixels x the fused samples
-        achieved = bytes_per_sample * samples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        valu_insts = None
-        # the render stage runs the pooled schedule (k_render_pool) unless VRT_RENDER=fused asks for the fused one
+        samples_per_launch = st["path_samples"] / launches  # a launch renders this rank's pixels x the fused samples
+        counters, counters_note = measured_counters(lib) if world == 1 else ({}, None)
         render_kernel = "k_render" if os.environ.get("VRT_RENDER") == "fused" else "k_render_pool"
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile) and world == 1:  # measured on the one-GPU launch (whole frame); a tile's launch moves less
-            try:
-                tj = json.load(open(tfile))
-                traffic = tj.get(f"{render_kernel}_bytes_per_launch")
-                valu_insts = tj.get(f"{render_kernel}_valu_wave_insts_per_launch")
-            except Exception:
-                traffic = None
+        flags = st.get("pipeline_flags", 0)
+        note = ("HBM is the bound the tier names; the 128^3 working set (8.3 MB) is cache resident and the kernel is bound by vector-instruction "
+                "issue under divergence at 2 waves per SIMD (DESIGN.md 7); `achieved` counts the bytes of the schedule that is timed (fused "
+                "samples share their camera rays: queries counted once), `reference_algorithm` the bytes the reference would move for the same "
+                "paths. Launches overlap: the duration is a launch's span, the step period is ms_per_step")
+        if counters_note:
+            note += "; " + counters_note
         out = {
             "metric": "Mpath-samples/sec at 1920x1080, 8 bounces", "value": round(value, 3), "unit": "Mpath-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "example1-style scene S1 (scenes.scene_s1), 128^3 grid, 1920x1080, 4 spp/step, 8 bounces, "
                                    "static camera, ReSTIR off", "width": WIDTH, "height": HEIGHT, "spp_per_step": SPP_PER_STEP,
-                       "max_depth": MAX_DEPTH, "seed": SEED, "sharding": (f"{world} contiguous row tiles, boundaries balanced by measured tile cost, RCCL gather per step; "
+                       "max_depth": MAX_DEPTH, "seed": SEED, "build_id": lib.vrt_build_id().decode(),
+                       "launch_pipeline": {"overlapped": bool(flags & 1), "dispatch_gate": bool(flags & 2), "gate_host_releases": int(flags >> 8)},
+                       "sharding": (f"{world} contiguous row tiles, boundaries balanced by measured tile cost, RCCL gather per step, "
+                                    f"{parallel.reserved_cus(world)} CUs' worth of workgroup slots left free for the collective; "
                                     f"tile rows {[b - a for a, b in bounds]}") if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": render_kernel, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "algorithmic_bytes_per_path_sample": round(bytes_per_sample, 2),
-                         "queries_per_path_sample": round(q, 2), "closest_hits_per_path_sample": round(hc, 3),
-                         "path_samples_per_launch": int(samples_per_launch), "render_ms_per_launch": round(avg_ms, 4),
-                         "temporal_ms_per_launch": round(st["temporal_ms"] / max(st["temporal_launches"], 1), 4),
-                         # what actually bounds the kernel: wave-level VALU instructions per launch (PMC, profiles/traffic.json)
-                         # over the live launch duration, against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
-                         "valu_issue": ({"achieved": round(valu_insts / (avg_ms * 1e-3) / 1e9, 2), "peak": 614.4, "unit": "G wave-instructions/s",
-                                         "frac": round(valu_insts / (avg_ms * 1e-3) / 614.4e9, 4)} if (valu_insts and avg_ms > 0) else None),
-                         "note": "HBM is the bound the tier names; the 128^3 working set is cache resident and the kernel is "
-                                 "VALU-issue bound (profiles/r01_v10_pmc_k_render_pool.txt). Launches overlap: "
-                                 "the duration is a launch's span, the step period is ms_per_step"},
+            "roofline": roofline_block(render_kernel, avg_ms, samples_per_launch, render_bytes(work["reference"]), render_bytes(work["timed"]),
+                                       counters.get("config2_s1_1080p", {}), note),
+            "work_per_path_sample": {k: {a: round(b, 3) for a, b in v.items()} for k, v in work.items()},
+            "kernel_ms_per_launch": {"render": round(avg_ms, 4), "temporal": round(st["temporal_ms"] / max(st["temporal_launches"], 1), 4)},
         }
-        if not args.no_cpu_baseline and world == 1:
-            cb, ref_rows, rr = cpu_baseline(mat, rgb, params)
-            out["cpu_baseline"] = cb
-        else:
-            out["cpu_baseline"] = None
+    sess.close()
+    if rank == 0:
+        out["secondary"] = None
+        if world == 1 and not args.no_secondary:
+            sec = []
+            for case in SECONDARY:
+                try:
+                    sec.append(run_secondary(lib, case, counters))
+                except Exception as e:  # a secondary leg must not take the headline down
+                    sec.append({"config": case["config"], "name": case["name"], "error": f"{type(e).__name__}: {e}"})
+            out["secondary"] = sec
+        out["cpu_baseline"] = cpu_baseline(mat, rgb, params) if (not args.no_cpu_baseline and world == 1) else None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    sess.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,181 @@
+"""The launch pipeline around the render kernels on the GPU: overlapped launches, the dispatch gate and its host release,
+error roll-back, the workgroup-slot reservation of multi-GPU runs, and RCCL beside the library's own streams."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+import orc
+from voxel_rt2_amd import _lib, host, scenes
+from voxel_rt2_amd._session import NativeSession
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, DEPTH = 640, 360, 6
+
+
+def render(calls=(4, 4, 4, 3, 4), reserve=None):
+    mat, rgb, params = scenes.scene_sunlit(0)
+    cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=DEPTH, seed=5)
+    s = NativeSession(_lib.load(), "vrt_", cfg)
+    if reserve is not None:
+        s.reserve_cus(reserve)
+    orc.setup(s, mat, rgb, params)
+    for n in calls:
+        s.accumulate(n)
+    hdr, st = s.fetch_hdr(), s.stats()
+    s.close()
+    return hdr, st
+
+
+@pytest.fixture(scope="module")
+def reference_frame():
+    os.environ["VRT_OVERLAP"] = "0"
+    try:
+        hdr, st = render()
+    finally:
+        os.environ.pop("VRT_OVERLAP", None)
+    assert st["pipeline_flags"] & 1 == 0
+    return hdr
+
+
+def test_overlapped_launches_with_gate(reference_frame):
+    hdr, st = render()
+    assert st["pipeline_flags"] & 3 == 3, "overlapped launches with the dispatch gate are the default on a plain GPU box"
+    assert st["pipeline_flags"] >> 8 <= 1   # only the release at context teardown may have happened
+    assert np.array_equal(hdr.view(np.uint32), reference_frame.view(np.uint32))
+
+
+def test_gate_left_out(reference_frame, monkeypatch):
+    monkeypatch.setenv("VRT_DRAIN_GATE", "0")
+    hdr, st = render()
+    assert st["pipeline_flags"] & 3 == 1
+    assert np.array_equal(hdr.view(np.uint32), reference_frame.view(np.uint32))
+
+
+def test_host_release_of_the_gate_changes_nothing(reference_frame, monkeypatch):
+    """The watchdog that releases a stuck dispatch gate from the host, made to fire on every synchronisation: the gate
+    only times dispatches (ordering is by events), so results are the same."""
+    monkeypatch.setenv("VRT_GATE_WATCHDOG_MS", "0.0001")
+    mat, rgb, params = scenes.scene_sunlit(0)
+    cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=DEPTH, seed=5)
+    s = NativeSession(_lib.load(), "vrt_", cfg)
+    orc.setup(s, mat, rgb, params)
+    for n in (4, 4, 4, 3, 4):
+        s.accumulate(n)
+        s.sync()
+    hdr, st = s.fetch_hdr(), s.stats()
+    s.close()
+    assert st["pipeline_flags"] >> 8 >= 2
+    assert np.array_equal(hdr.view(np.uint32), reference_frame.view(np.uint32))
+
+
+def test_reserved_workgroup_slots_change_nothing(reference_frame):
+    hdr, _ = render(reserve=8)
+    assert np.array_equal(hdr.view(np.uint32), reference_frame.view(np.uint32))
+    hdr, _ = render(reserve=200)
+    assert np.array_equal(hdr.view(np.uint32), reference_frame.view(np.uint32))
+
+
+def test_camera_ray_records_under_contention():
+    """Fused samples share camera-ray records across CUs (vrt_pool.h).  Short work ranges make readers race writers: a
+    135-row shard (one GPU of eight at 1080p) and a 16-row one, each against the same rows of the unsharded frame."""
+    mat, rgb, params = scenes.scene_s1(0)
+    Wf, Hf = 1920, 1080
+
+    def run(rows):
+        cfg = host.make_config(Wf, Hf, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=8, seed=0, rows=rows)
+        s = NativeSession(_lib.load(), "vrt_", cfg)
+        orc.setup(s, mat, rgb, params)
+        for _ in range(3):
+            s.accumulate(4)
+        out = s.fetch_hdr()
+        s.close()
+        return out
+
+    full = run(None)
+    for rows in ((405, 540), (536, 552), (0, 8)):
+        part = run(rows)
+        assert np.array_equal(part[rows[0]:rows[1]].view(np.uint32), full[rows[0]:rows[1]].view(np.uint32)), rows
+
+
+def test_accumulate_failure_rolls_back(monkeypatch):
+    """A launch that fails to queue (injected: VRT_TEST_FAIL_LAUNCH) returns an error, leaves nobody waiting at the dispatch
+    gate, and the context renders on afterwards -- with the result of a context that never saw the failure."""
+    lib = _lib.load()
+    mat, rgb, params = scenes.scene_sunlit(0)
+    cfg = host.make_config(320, 200, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=4, seed=2)
+    good = NativeSession(lib, "vrt_", cfg)
+    orc.setup(good, mat, rgb, params)
+    for n in (4, 4, 4):
+        good.accumulate(n)
+    want = good.fetch_hdr()
+    good.close()
+    s = NativeSession(lib, "vrt_", cfg)
+    orc.setup(s, mat, rgb, params)
+    s.accumulate(4)
+    s.accumulate(4)
+    monkeypatch.setenv("VRT_TEST_FAIL_LAUNCH", "2")
+    assert lib.vrt_accumulate(C.c_void_p(s._ctx), 4) == -2 and b"injected" in lib.vrt_last_error()
+    monkeypatch.delenv("VRT_TEST_FAIL_LAUNCH")
+    assert lib.vrt_accumulate(C.c_void_p(s._ctx), -1) == -1
+    s.accumulate(4)
+    assert s.stats()["pipeline_flags"] >> 8 >= 1   # the failed launch's gate was released from the host
+    assert np.array_equal(s.fetch_hdr().view(np.uint32), want.view(np.uint32))
+    s.close()
+
+
+def test_rccl_beside_the_library():
+    """backend='nccl' (RCCL) at world size 1 in a process that has loaded libvrt_hip.so FIRST and rendered: one HIP runtime
+    shared with torch (_lib._share_hip_runtime_with_torch), RCCL's streams beside the library's, a gather + all_reduce between
+    render launches, and the frame unchanged by it."""
+    code = textwrap.dedent("""
+        import os, sys, json
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np
+        from voxel_rt2_amd import _lib, host, scenes, parallel, materials
+        from voxel_rt2_amd._session import NativeSession
+        lib = _lib.load()
+        import torch, torch.distributed as dist
+        mat, rgb, params = scenes.scene_sunlit(0)
+        cfg = host.make_config(480, 270, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=5, seed=3)
+        def session():
+            s = NativeSession(lib, "vrt_", cfg)
+            s.upload_voxels(mat, rgb); s.upload_materials(materials.load_table())
+            s.set_scene(host.make_scene_params(**params)); s.set_camera(host.default_camera(480, 270, jitter_index=1)); s.prepare()
+            return s
+        a = session()
+        for _ in range(3): a.accumulate(4)
+        want = a.fetch_hdr(); a.close()
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%%d" %% int(sys.argv[1]), rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        b = session()
+        stream = torch.cuda.Stream()
+        b.set_stream(stream.cuda_stream)
+        parallel.configure_session(b, 2)   # as a rank of a larger group would
+        tile = torch.zeros((270, 480, 3), dtype=torch.float32, device="cuda")
+        got = [torch.zeros_like(tile)]
+        for _ in range(3):
+            with torch.cuda.stream(stream):
+                b.accumulate(4)
+                b.fetch_hdr_device_async(tile.data_ptr())
+                dist.gather(tile, got, dst=0)
+                t = torch.ones(8, device="cuda"); dist.all_reduce(t)
+        stream.synchronize(); torch.cuda.synchronize()
+        same = bool(np.array_equal(got[0].cpu().numpy().view(np.uint32), want.view(np.uint32)))
+        print(json.dumps(dict(same=same, backend=dist.get_backend(), queues=os.environ.get("GPU_MAX_HW_QUEUES"))))
+        dist.destroy_process_group(); b.close()
+    """) % (ROOT, ROOT)
+    import socket
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GPU_MAX_HW_QUEUES")}
+    r = subprocess.run([sys.executable, "-c", code, str(port)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out == dict(same=True, backend="nccl", queues="8")

@@ -515,6 +515,10 @@ static void abort_pipeline(vrt_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipGetLastError();
     resolve_events(c);
+    // the work heads rotate with the launch number and each launch zeroes the set two launches ahead: a launch that did not
+    // run leaves a used set behind -- nothing is in flight now, so all four start clean
+    (void)hipMemset(c->d_work, 0, 4 * VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE * sizeof(unsigned));
+    (void)hipGetLastError();
     c->ev_t_valid[0] = c->ev_t_valid[1] = c->ev_t_valid[2] = false;
     c->main_dirty = true;
     c->render_blocks = 0;   // residency and scratch are looked at again
@@ -636,6 +640,8 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         if (record(c, 0, &a, &b) != VRT_OK) return VRT_E_DEVICE;
         HIP_TRY(hipEventRecord(a, rs));
         const unsigned seq = c->launch_seq++;
+        // test hook (tests/test_gpu_pipeline.py): launch number VRT_TEST_FAIL_LAUNCH is reported as failed instead of queued
+        if (const char* e = getenv("VRT_TEST_FAIL_LAUNCH")) { if ((unsigned)atoi(e) == seq) return fail(VRT_E_DEVICE, "injected launch failure (VRT_TEST_FAIL_LAUNCH)"); }
         PrimaryRecord* prim = nullptr;  // fused samples share their camera rays through this table (vrt_pool.h)
         if (c->pooled && g > 1 && (!instr || c->count_as_timed)) {  // counting the reference's work: every camera ray is walked
             const int which = (overlapped && lane_of) ? 1 : 0;
