@@ -55,6 +55,13 @@ int orc_upload_cloud_texture(orc_ctx* c, const uint8_t* rgb) {
     memcpy(c->r.atmos.cloud_tex.data(), rgb, 256 * 256 * 3);
     return 0;
 }
+/* test plumbing: install sky tables computed elsewhere (the GPU's, whose equality with this oracle's own tables is tested at
+ * small sizes) so that a full-size frame can be checked without the hours the 3840^2 precompute takes on a CPU */
+int orc_upload_sky(orc_ctx* c, const float* scat, const float* trans) {
+    memcpy(c->r.atmos.skybox_scattering.data(), scat, c->r.atmos.skybox_scattering.size() * 12);
+    memcpy(c->r.atmos.skybox_transmittance.data(), trans, c->r.atmos.skybox_transmittance.size() * 12);
+    return 0;
+}
 int orc_set_scene(orc_ctx* c, const vrt_scene_params* s) {
     Renderer& r = c->r;
     r.floor_height = s->floor_height;
@@ -154,6 +161,25 @@ void orc_unit_next_hit(orc_ctx* c, const float* o, const float* d, int shadow, f
 void orc_unit_cast_dir(orc_ctx* c, int u, int v, float* out) {
     V3 d = c->r.get_cast_dir((float)u, (float)v);
     out[0] = d.x; out[1] = d.y; out[2] = d.z;
+}
+static DisneyMaterial mat_from(const float* m);
+/* pathtracer.py:672-812 on an UNSTORED sample: shift(dst_pos, dst_normal, dst_material, src_pos, sample).  `sample` = 23 floats:
+ * F, rc_pos, rc_normal, rc_incident_dir, rc_incident_L, rc_NEE_dir (3 each), rc_mat_info (bit pattern), cached_jacobian_term,
+ * lobes.  out: diffuse rgb, specular rgb, jacobian. */
+void orc_unit_shift(orc_ctx* c, const float* dst_pos, const float* dst_n, const float* dst_mat, const float* src_pos, const float* sample,
+                    float* out) {
+    Reservoir r;
+    r.init();
+    const float* p = sample;
+    auto rd = [&]() { V3 v = v3(p[0], p[1], p[2]); p += 3; return v; };
+    r.z.F = rd(); r.z.rc_pos = rd(); r.z.rc_normal = rd(); r.z.rc_incident_dir = rd(); r.z.rc_incident_L = rd(); r.z.rc_NEE_dir = rd();
+    r.z.rc_mat_info = dm_f2u(p[0]); r.z.cached_jacobian_term = p[1]; r.z.lobes = (int)p[2];
+    r.M = 1.0f; r.weight = 1.0f;
+    V3 d = v3(0.0f), sp = v3(0.0f);
+    float jac = 0.0f;
+    c->r.shift(v3(dst_pos[0], dst_pos[1], dst_pos[2]), v3(dst_n[0], dst_n[1], dst_n[2]), mat_from(dst_mat), v3(src_pos[0], src_pos[1], src_pos[2]), r,
+               &d, &sp, &jac, nullptr);
+    out[0] = d.x; out[1] = d.y; out[2] = d.z; out[3] = sp.x; out[4] = sp.y; out[5] = sp.z; out[6] = jac;
 }
 static DisneyMaterial mat_from(const float* m) {
     DisneyMaterial dm;

@@ -49,6 +49,12 @@ class Oracle(NativeSession):
         super().__init__(lib(), "orc_", cfg, create_extra=(C.c_int(threads),))
         self.threads = threads
 
+    def upload_sky(self, scat, trans):
+        scat = np.ascontiguousarray(scat, dtype=np.float32)
+        trans = np.ascontiguousarray(trans, dtype=np.float32)
+        assert scat.shape == trans.shape == (self.cfg.sky_res, self.cfg.sky_res, 3)
+        self._lib.orc_upload_sky(C.c_void_p(self._ctx), fptr(scat), fptr(trans))
+
     # single-function probes ---------------------------------------------------------------
     def query_occupancy(self, x, y, z, lod):
         return bool(self._lib.orc_unit_query_occupancy(C.c_void_p(self._ctx), int(x), int(y), int(z), int(lod)))

@@ -1,0 +1,68 @@
+"""BASELINE configs 3 and 4 at their real frame sizes on the GPU, against the oracle on a row shard (the oracle renders
+16 rows of a 1080p / 4K frame in seconds; per-pixel random streams make a shard's pixels those of the full frame)."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from voxel_rt2_amd import _abi, _lib, host, scenes
+from voxel_rt2_amd._session import NativeSession
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config4_full_size_shard_matches_oracle():
+    """Config 4's frame -- dense 128^3 fill (p = 0.5, seed 12345), 3840x2160, 8 bounces, one fused call of 4 samples -- on the
+    16 rows that hold pixel (3839, 2159): the pooled kernel packs u, v in 12 bits each and 3840 is 94 % of that range.  Then the
+    whole frame on one GPU: same rows, bit for bit."""
+    W, H, rows = 3840, 2160, (2144, 2160)
+    mat, rgb, params = scenes.scene_dense(12345)
+    kw = dict(voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=8, seed=0)
+    g, o = NativeSession(_lib.load(), "vrt_", host.make_config(W, H, rows=rows, **kw)), orc.Oracle(host.make_config(W, H, rows=rows, **kw), threads=16)
+    for s in (g, o):
+        orc.setup(s, mat, rgb, params)
+        s.accumulate(4)
+    a, b = g.fetch_hdr()[rows[0]:rows[1]], o.fetch_hdr()[rows[0]:rows[1]]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a != b).sum()} values differ"
+    for which in (_abi.BUF_GBUF_DEPTH, _abi.BUF_GBUF_NORMAL, _abi.BUF_GBUF_MAT, _abi.BUF_HISTORY_DIFFUSE, _abi.BUF_HISTORY_SPECULAR):
+        assert np.array_equal(g.fetch_buffer(which)[rows[0]:rows[1]].view(np.uint8), o.fetch_buffer(which)[rows[0]:rows[1]].view(np.uint8)), which
+    g.close(); o.close()
+    f = NativeSession(_lib.load(), "vrt_", host.make_config(W, H, **kw))
+    orc.setup(f, mat, rgb, params)
+    f.accumulate(4)
+    full = f.fetch_hdr()
+    f.close()
+    assert np.array_equal(full[rows[0]:rows[1]].view(np.uint32), a.view(np.uint32))
+    assert np.isfinite(full).all() and full[:, -1].mean() > 0.01 and full[-1].mean() > 0.01   # the last column and row were rendered
+
+
+def test_config3_full_size_shard_matches_oracle():
+    """Config 3 as benchmarked -- scene S6, physical sky + clouds with the 3840^2 tables, ReSTIR spatial reuse, 1920x1080,
+    8 bounces -- on a 16-row shard through the horizon (26 halo rows each side for the reuse radius), two accumulate passes.
+    The sky tables are computed on the GPU (6 s; the CPU would need hours) and handed to the oracle; that both sides compute
+    the same tables is tested at small sizes (test_sky_precompute_and_lookup_match_oracle)."""
+    W, H, rows, R = 1920, 1080, (560, 576), 3840
+    mat, rgb, params = scenes.scene_s6(0)
+    cloud = np.load(os.path.join(ROOT, "voxel_rt2_amd", "data", "cloud_texture.npy"))
+    cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=8, seed=0, use_restir=True, sky_res=R,
+                           rows=rows)
+    g = NativeSession(_lib.load(), "vrt_", cfg)
+    orc.setup(g, mat, rgb, params, cloud=cloud)
+    for _ in range(32):
+        g.sky_accumulate_clouds(32)
+    for sl in range(32):
+        g.sky_compute_slice(sl, 32)
+    scat, trans = g.fetch_buffer(_abi.BUF_SKY_SCATTERING), g.fetch_buffer(_abi.BUF_SKY_TRANSMITTANCE)
+    assert np.isfinite(scat).all() and np.isfinite(trans).all() and scat.max() > 0
+    o = orc.Oracle(cfg, threads=16)
+    orc.setup(o, mat, rgb, params, cloud=cloud)   # prepare_data builds the (cheap) LUT and cloud ambient; the slices are what is slow
+    o.upload_sky(scat, trans)
+    for s in (g, o):
+        s.accumulate(2)
+    a, b = g.fetch_hdr()[rows[0]:rows[1]], o.fetch_hdr()[rows[0]:rows[1]]
+    assert np.isfinite(a).all() and a.mean() > 0.01
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a != b).sum()} of {a.size} values differ"
+    for which in (_abi.BUF_GBUF_DEPTH, _abi.BUF_GBUF_NORMAL, _abi.BUF_GBUF_MAT, _abi.BUF_HISTORY_DIFFUSE, _abi.BUF_HISTORY_SPECULAR):
+        assert np.array_equal(g.fetch_buffer(which)[rows[0]:rows[1]].view(np.uint8), o.fetch_buffer(which)[rows[0]:rows[1]].view(np.uint8)), which
