@@ -42,6 +42,8 @@ def run(case):
     cfg = host.make_config(case["W"], case["H"], voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=case["depth"],
                            seed=0, use_restir=case.get("restir", False), sky_res=sky_res, rows=case.get("rows"), grid_res=case.get("grid", 128))
     s = NativeSession(lib, "vrt_", cfg)
+    if os.environ.get("VRT_BENCH_RESERVE"):   # one GPU's cost of the workgroup slots a multi-GPU rank leaves to RCCL
+        s.reserve_cus(int(os.environ["VRT_BENCH_RESERVE"]))
     s.upload_voxels(mat, rgb)
     s.upload_materials(materials.load_table())
     if sky_res:
