@@ -178,16 +178,16 @@ static void render_all(Emu* c, const FrameParams& fp, const SceneData& sc, const
 // The pool kernel's stage functions (vrt_pool.h) stepped one path at a time: the record goes through the same
 // packed slot (here a 25-dword array) and scratch line as on the device, and every walk is suspended and
 // resumed every third step so that the packing of a half-done walk is exercised too.
-template <int G>
+template <int G, bool RESTIR>
 static void render_all_pool(Emu* c, const FrameParams& fp, const SceneData& sc, const PixelBuffers& out) {
     GlobalPyramid<G> P;
     P.p = sc.pyr;
     // the launcher's choice of kernel variant (vrt_kernels.hip, launch_render_pool)
-    const bool black_sun = !((fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f);
+    const bool black_sun = !RESTIR && !((fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f);
     for (int v = fp.row0; v < fp.row1; v++)
         for (int u = 0; u < fp.W; u++) {
             if (outside_render_area(fp, (float)u, (float)v)) continue;
-            uint32_t slot[PF_COUNT] = {0}, cold[PC_COUNT] = {0};
+            uint32_t slot[PF_COUNT] = {0}, cold[ColdLine<RESTIR>::count] = {0};
             SlotRef s{slot, 1};
             int st = pool_begin<G>(fp, s, u, v, 0, c->ts);
             while (st != SLOT_EMPTY) {
@@ -209,10 +209,11 @@ static void render_all_pool(Emu* c, const FrameParams& fp, const SceneData& sc, 
                     walk_store(s, w);
                     st = slot_state_after_walk<G>(w.t, s.f(PF_FLOOR_T));
                 } else if (st == SLOT_SHADE) {
-                    st = black_sun ? pool_shade<HIT_SOMETHING, true>(fp, sc, P, out, s, cold, c->ts)
-                                   : pool_shade<HIT_SOMETHING, false>(fp, sc, P, out, s, cold, c->ts);
+                    if constexpr (RESTIR) st = pool_shade<HIT_SOMETHING, false, true>(fp, sc, P, out, s, cold, c->ts);
+                    else st = black_sun ? pool_shade<HIT_SOMETHING, true>(fp, sc, P, out, s, cold, c->ts)
+                                        : pool_shade<HIT_SOMETHING, false>(fp, sc, P, out, s, cold, c->ts);
                 } else {
-                    st = pool_shade<HIT_NOTHING, false>(fp, sc, P, out, s, cold, c->ts);
+                    st = pool_shade<HIT_NOTHING, false, RESTIR>(fp, sc, P, out, s, cold, c->ts);
                 }
             }
         }
@@ -244,7 +245,8 @@ static int accumulate_g(Emu* c, int n_samples) {
         const f3* cd = rt;
         const f3* cs = c->color_s.data();
         if (c->cfg.use_restir) {
-            render_all<G, true>(c, fp, sc, out);
+            if (getenv("VRT_EMU_POOL")) render_all_pool<G, true>(c, fp, sc, out);
+            else render_all<G, true>(c, fp, sc, out);
             GrisBuffers gb;
             gb.color_d_in = rt; gb.color_s_in = c->color_s.data();
             gb.color_d_out = c->color_d2.data(); gb.color_s_out = c->color_s2.data();
@@ -270,7 +272,7 @@ static int accumulate_g(Emu* c, int n_samples) {
             cd = c->color_d2.data();
             cs = c->color_s2.data();
         } else if (getenv("VRT_EMU_POOL")) {
-            render_all_pool<G>(c, fp, sc, out);
+            render_all_pool<G, false>(c, fp, sc, out);
         } else {
             render_all<G, false>(c, fp, sc, out);
         }

@@ -66,3 +66,30 @@ def test_config3_full_size_shard_matches_oracle():
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a != b).sum()} of {a.size} values differ"
     for which in (_abi.BUF_GBUF_DEPTH, _abi.BUF_GBUF_NORMAL, _abi.BUF_GBUF_MAT, _abi.BUF_HISTORY_DIFFUSE, _abi.BUF_HISTORY_SPECULAR):
         assert np.array_equal(g.fetch_buffer(which)[rows[0]:rows[1]].view(np.uint8), o.fetch_buffer(which)[rows[0]:rows[1]].view(np.uint8)), which
+
+
+def test_restir_row_shards_equal_full_frame():
+    """Row shards with spatial reuse on (26 halo rows): the tap angles of a pixel are hashed from its 8x8 tile in FRAME
+    coordinates (pathtracer.py:834-836) and the kernel works them out once per wave, so its wave tiles must sit on that grid
+    whatever row a shard starts at.  (Round 1's kernel started them at the shard's first row: a shard whose start was not
+    2 modulo 8 -- every tile of an 8-GPU split of 1080 rows but one -- got other taps than the full frame.)"""
+    W, H = 208, 136
+    mat, rgb, params = scenes.scene_sunlit(0)
+    kw = dict(voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=5, seed=13, use_restir=True)
+
+    def run(rows):
+        s = NativeSession(_lib.load(), "vrt_", host.make_config(W, H, rows=rows, **kw))
+        orc.setup(s, mat, rgb, params)
+        s.accumulate(2)
+        out = s.fetch_hdr()
+        s.close()
+        return out
+
+    full = run(None)
+    for rows in ((0, 17), (17, 34), (34, 51), (51, 68), (68, 85), (85, 102), (102, 119), (119, 136), (33, 90)):
+        part = run(rows)
+        assert np.array_equal(part[rows[0]:rows[1]].view(np.uint32), full[rows[0]:rows[1]].view(np.uint32)), rows
+    o = orc.Oracle(host.make_config(W, H, **kw), threads=16)
+    orc.setup(o, mat, rgb, params)
+    o.accumulate(2)
+    assert np.array_equal(full.view(np.uint32), o.fetch_hdr().view(np.uint32))

@@ -482,7 +482,7 @@ static bool ensure_overlap(vrt_ctx* c) {
         ok = dalloc(&c->alt_multi_d[s], n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->alt_spec_planes[s], n * VRT_MAX_FUSED) == hipSuccess &&
              dalloc(&c->alt_refl_planes[s], n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->alt_gb_pos[s], n) == hipSuccess &&
              dalloc(&c->alt_gb_mat[s], n) == hipSuccess && hipStreamCreateWithFlags(&c->rstream[s], hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->alt_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->render_blocks)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->alt_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks)) == hipSuccess;
     for (int s = 0; s < 3 && ok; s++)
         ok = hipEventCreateWithFlags(&c->ev_r[s], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_t[s], hipEventDisableTiming) == hipSuccess;
@@ -544,13 +544,13 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         // (a wave owns a pool of paths in LDS and works stage by stage, vrt_pool.h).  The pooled kernel packs pixel
         // coordinates in 12 bits and the depth in 4 and carries no ReSTIR state, so contexts outside that use the
         // fused one.  VRT_RENDER=fused selects the fused kernel everywhere (A/B measurements, tests).
-        bool pooled = !restir && c->cfg.width <= 4096 && c->cfg.height <= 4096 && c->cfg.max_depth <= 15;
+        bool pooled = c->cfg.width <= 4096 && c->cfg.height <= 4096 && c->cfg.max_depth <= 15;
         if (const char* e = getenv("VRT_RENDER")) {
             if (strcmp(e, "fused") == 0) pooled = false;
             else if (strcmp(e, "pool") != 0) return fail(VRT_E_INVALID, "VRT_RENDER must be 'fused' or 'pool'");
         }
         int per_cu = 0;
-        if (pooled) HIP_TRY(query_render_pool_residency(c->cfg.grid_res, instr, &per_cu));
+        if (pooled) HIP_TRY(query_render_pool_residency(c->cfg.grid_res, restir, instr, &per_cu));
         else HIP_TRY(query_render_residency(c->cfg.grid_res, restir, instr, &per_cu));
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
@@ -561,10 +561,10 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         if (pooled) {
             HIP_TRY(sync_guarded(c, c->stream));
             if (c->d_pool_scratch) { HIP_TRY(hipFree(c->d_pool_scratch)); c->d_pool_scratch = nullptr; }
-            HIP_TRY(hipMalloc((void**)&c->d_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->render_blocks)));
+            HIP_TRY(hipMalloc((void**)&c->d_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks)));
             if (c->overlap_ready) {  // the second render stream's scratch follows
                 if (c->alt_pool_scratch) { HIP_TRY(hipFree(c->alt_pool_scratch)); c->alt_pool_scratch = nullptr; }
-                HIP_TRY(hipMalloc((void**)&c->alt_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->render_blocks)));
+                HIP_TRY(hipMalloc((void**)&c->alt_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks)));
             }
         }
     }
@@ -648,7 +648,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             if (!c->d_prim_cache[which] && dalloc(&c->d_prim_cache[which], c->npix) != hipSuccess) { (void)hipGetLastError(); c->d_prim_cache[which] = nullptr; }
             prim = c->d_prim_cache[which];
         }
-        if (c->pooled) HIP_TRY(launch_render_pool(rs, c->cfg.grid_res, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch : c->d_pool_scratch, c->drain_signal, prim));
+        if (c->pooled) HIP_TRY(launch_render_pool(rs, c->cfg.grid_res, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch : c->d_pool_scratch, c->drain_signal, prim));
         else HIP_TRY(launch_render(rs, c->cfg.grid_res, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g));
         c->drain_signalled = c->pooled && c->drain_signal != nullptr;
         HIP_TRY(hipEventRecord(b, rs));

@@ -39,11 +39,11 @@ hipError_t launch_prepare(hipStream_t st, int grid_res, const int8_t* mat, const
 hipError_t query_render_residency(int grid_res, bool restir, bool instr, int* blocks_per_cu);
 hipError_t launch_render(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                          const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples);
-// pooled schedule (vrt_pool.h), ReSTIR off only.  `cold` holds pool_scratch_bytes(grid_res, n_blocks) bytes.
-hipError_t query_render_pool_residency(int grid_res, bool instr, int* blocks_per_cu);
+// pooled schedule (vrt_pool.h).  `cold` holds pool_scratch_bytes(grid_res, restir, n_blocks) bytes.
+hipError_t query_render_pool_residency(int grid_res, bool restir, bool instr, int* blocks_per_cu);
 int pool_waves_per_block(int grid_res);
-size_t pool_scratch_bytes(int grid_res, int n_blocks);
-hipError_t launch_render_pool(hipStream_t st, int grid_res, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
+size_t pool_scratch_bytes(int grid_res, bool restir, int n_blocks);
+hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                               const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold,
                               uint32_t* drain_signal,   // signal memory (or null): receives launch_seq + 1 when the launch starts to drain
                               PrimaryRecord* prim_cache);       // per-pixel camera-ray records shared by the fused samples (or null), npix entries

@@ -281,13 +281,14 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-template <int G, bool INSTR, bool BLACK_SUN>
+template <int G, bool RESTIR, bool INSTR, bool BLACK_SUN>
 // 208 registers per wave (the attribute counts half of the unified file): two waves per SIMD then leave the 96 that
 // k_temporal runs in beside them (see there).  The allocator would take 238; the cap costs 28 bytes of scratch.
+// The ReSTIR instantiation (no overlapped launches, so nothing runs beside it) takes the two-wave maximum of 256.
 #ifndef VRT_POOL_HALF_VGPRS
 #define VRT_POOL_HALF_VGPRS 104
 #endif
-__global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(VRT_POOL_HALF_VGPRS))) void k_render_pool(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
+__device__ __forceinline__ void render_pool_body(const FrameParams& fp, const SceneData& sc, const PixelBuffers& out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
     constexpr int WAVES = PoolGeom<G>::waves;
     constexpr bool BIG = (G == 256);   // which coarse levels are staged how: see LdsPyramid2
     __shared__ ulonglong2 s_l12[BIG ? 1 : 512];
@@ -331,7 +332,8 @@ __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attr
     __syncthreads();
     SceneData scl = sc;
     scl.mats = s_mats;
-    uint32_t* const cold_wave = cold + (size_t)(blockIdx.x * WAVES + wave) * VRT_POOL_SLOTS * PC_COUNT;
+    constexpr int COLD = ColdLine<RESTIR>::count;
+    uint32_t* const cold_wave = cold + (size_t)(blockIdx.x * WAVES + wave) * VRT_POOL_SLOTS * COLD;
 
     const int tiles_x = (fp.W + 7) >> 3;
     const int tiles_y = (fp.row1 - fp.row0 + 7) >> 3;
@@ -494,13 +496,13 @@ __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attr
                 const int slot = (int)list[lane];
                 SlotRef s;
                 s.base = pool + slot; s.stride = VRT_POOL_SLOTS;
-                uint32_t* const cold_line = cold_wave + slot * PC_COUNT;
+                uint32_t* const cold_line = cold_wave + slot * COLD;
                 if (stage == SLOT_SHADE) {
                     VRT_REGION(11);
-                    state[slot] = (uint32_t)pool_shade<HIT_SOMETHING, BLACK_SUN>(fp, scl, P, out, s, cold_line, ts);
+                    state[slot] = (uint32_t)pool_shade<HIT_SOMETHING, BLACK_SUN, RESTIR>(fp, scl, P, out, s, cold_line, ts);
                 } else if (stage == SLOT_ESCAPE) {
                     VRT_REGION(12);
-                    state[slot] = (uint32_t)pool_shade<HIT_NOTHING, false>(fp, scl, P, out, s, cold_line, ts);
+                    state[slot] = (uint32_t)pool_shade<HIT_NOTHING, false, RESTIR>(fp, scl, P, out, s, cold_line, ts);
                 } else {
                     VRT_REGION(13);
                     const unsigned my = base + (unsigned)lane;
@@ -535,13 +537,22 @@ __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attr
 #endif
     if (INSTR) flush_stats(ts, sc.counters);
 }
+// (the register attribute takes a literal, hence one kernel per budget around the shared body)
+template <int G, bool INSTR, bool BLACK_SUN>
+__global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(VRT_POOL_HALF_VGPRS))) void k_render_pool(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
+    render_pool_body<G, false, INSTR, BLACK_SUN>(fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, drain_value, prim_cache);
+}
+template <int G, bool INSTR>
+__global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(128))) void k_render_pool_restir(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
+    render_pool_body<G, true, INSTR, false>(fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, drain_value, prim_cache);
+}
 
 // ---- spatial reuse ---------------------------------------------------------------------------
 template <int G, bool INSTR>
 #ifndef VRT_GRIS_MIN_WAVES
 #define VRT_GRIS_MIN_WAVES 2   // 256 registers, no spills; one wave per SIMD left the VALU idle a third of the time (6.6 vs 10.2 ms)
 #endif
-__global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES) void k_gris(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r1, int tiles_x, int band_w) {
+__global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES) void k_gris(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r_first, int r1, int tiles_x, int band_w) {
     constexpr int N1 = GridDim<G>::n1 * GridDim<G>::n1 * GridDim<G>::n1, N2 = GridDim<G>::n2 * GridDim<G>::n2 * GridDim<G>::n2;
     __shared__ unsigned long long s_l1[N1];
     __shared__ unsigned long long s_l2[N2];
@@ -567,6 +578,8 @@ __global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES) void k_gris(FrameParams fp
     const int bx = xcd * band_w + slot % band_w, by = slot / band_w;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int u = bx * 16 + (wave & 1) * 8 + (lane & 7);
+    // r0 is a multiple of 8: a wave's 8x8 pixels are then one tile of the tap-angle hash (u >> 3, v >> 3), whatever row the
+    // shard starts at; rows [r0, r_first) are not this launch's
     const int v = r0 + by * 16 + (wave >> 1) * 8 + (lane >> 3);
     if (lane < 32) gris_tap_cs(u, v, 0, lane, s_cs[wave]);
     __syncthreads();
@@ -574,7 +587,7 @@ __global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES) void k_gris(FrameParams fp
     taps.cs = s_cs[wave]; taps.off = &s_off[0][threadIdx.x]; taps.off_stride = 256;
     TraceStats ts;
     stats_zero(ts);
-    if (bx < tiles_x && u < fp.W && v < r1) gris_pixel(fp, scl, P, gbl, taps, u, v, 0, 24.0f, 32, 1, ts);
+    if (bx < tiles_x && u < fp.W && v >= r_first && v < r1) gris_pixel(fp, scl, P, gbl, taps, u, v, 0, 24.0f, 32, 1, ts);
     if (INSTR) flush_stats(ts, sc.counters);
 }
 
@@ -700,13 +713,16 @@ hipError_t launch_render(hipStream_t st, int grid_res, bool restir, bool instr, 
     return hipSuccess;
 }
 int pool_waves_per_block(int grid_res) { return grid_res == 256 ? PoolGeom<256>::waves : PoolGeom<128>::waves; }
-hipError_t query_render_pool_residency(int grid_res, bool instr, int* blocks_per_cu) {
+hipError_t query_render_pool_residency(int grid_res, bool restir, bool instr, int* blocks_per_cu) {
     hipError_t e = hipSuccess;
-    VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool<G, A, B>, 64 * PoolGeom<G>::waves, 0)));
+    if (restir) VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool_restir<G, A>, 64 * PoolGeom<G>::waves, 0)));
+    else VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool<G, A, B>, 64 * PoolGeom<G>::waves, 0)));
     return e;
 }
-size_t pool_scratch_bytes(int grid_res, int n_blocks) { return (size_t)n_blocks * pool_waves_per_block(grid_res) * VRT_POOL_SLOTS * PC_COUNT * sizeof(uint32_t); }
-hipError_t launch_render_pool(hipStream_t st, int grid_res, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
+size_t pool_scratch_bytes(int grid_res, bool restir, int n_blocks) {
+    return (size_t)n_blocks * pool_waves_per_block(grid_res) * VRT_POOL_SLOTS * (restir ? ColdLine<true>::count : ColdLine<false>::count) * sizeof(uint32_t);
+}
+hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                               const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold,
                               uint32_t* drain_signal, PrimaryRecord* prim_cache) {
     unsigned* work_counter = work_counters + (launch_seq & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
@@ -715,7 +731,11 @@ hipError_t launch_render_pool(hipStream_t st, int grid_res, bool instr, int n_bl
     // the signal carries launch_seq + 1 of the latest launch that has begun to drain
     // the black-sun variant (scene.py's default light) compiles the light sample out of the shading stage
     const bool black_sun = !((fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f);
-    VRT_BY_GRID(grid_res, VRT_BY_2(instr, black_sun, hipLaunchKernelGGL((k_render_pool<G, A, B>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u, prim_cache)));
+    if (restir) {  // the reservoir needs the light sample whatever the sun's colour
+        VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_render_pool_restir<G, A>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u, prim_cache)));
+    } else {
+        VRT_BY_GRID(grid_res, VRT_BY_2(instr, black_sun, hipLaunchKernelGGL((k_render_pool<G, A, B>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u, prim_cache)));
+    }
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
@@ -726,9 +746,12 @@ hipError_t launch_mat_derived(hipStream_t st, const float* mats, float* mats_x) 
 }
 hipError_t launch_gris(hipStream_t st, int grid_res, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1) {
     hipLaunchKernelGGL(k_gris_prepare, dim3((fp.W + 63) / 64, (fp.row1 - fp.row0 + 3) / 4), dim3(256), 0, st, fp, sc, gb);
-    const int tiles_x = (fp.W + 15) / 16, tiles_y = (r1 - r0 + 15) / 16, band_w = (tiles_x + 7) / 8;
+    // the tap angles of a pixel are hashed from its 8x8 tile in FRAME coordinates (pathtracer.py:834-836) and worked out once
+    // per wave: the wave tiles have to sit on that grid, so the launch starts at the multiple of 8 at or below r0
+    const int ra = r0 & ~7;
+    const int tiles_x = (fp.W + 15) / 16, tiles_y = (r1 - ra + 15) / 16, band_w = (tiles_x + 7) / 8;
     dim3 g(8 * band_w * tiles_y), b(256);
-    VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_gris<G, A>), g, b, 0, st, fp, sc, gb, r0, r1, tiles_x, band_w)));
+    VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_gris<G, A>), g, b, 0, st, fp, sc, gb, ra, r0, r1, tiles_x, band_w)));
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }

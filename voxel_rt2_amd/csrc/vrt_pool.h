@@ -54,7 +54,11 @@ enum {  // LDS columns of a slot (dwords)
     PF_ITERS = 24,
     PF_COUNT = 25
 };
-enum { PC_NEE_D = 0, PC_NEE_S = 3, PC_ALBEDO = 6, PC_PPOS = 9, PC_INVPDF = 12, PC_MAT = 13, PC_COUNT = 16 };  // scratch line
+enum { PC_NEE_D = 0, PC_NEE_S = 3, PC_ALBEDO = 6, PC_PPOS = 9, PC_INVPDF = 12, PC_MAT = 13, PC_COUNT = 16,   // scratch line
+       // ReSTIR: the reconnection state of PathRestir (vrt_path.h) follows -- it changes at every vertex, so the line is
+       // read and written by every SHADE / ESCAPE of a path, through L2
+       PC_RS = 16, PC_COUNT_RESTIR = 48 };
+template <bool RESTIR> struct ColdLine { static constexpr int count = RESTIR ? (int)PC_COUNT_RESTIR : (int)PC_COUNT; };
 
 // A slot's column in the pool: field f lives at base[f * stride].
 struct SlotRef {
@@ -122,6 +126,15 @@ VRT_DEV void path_cold_defaults(Path<RESTIR>& p) {
     p.primary_albedo = mk3(1.0f); p.primary_pos = mk3(0.0f);
     p.first_invpdf = 1.0f;
     p.primary_mat_info = 0u;
+    if constexpr (RESTIR) {  // as path_begin leaves them
+        p.rs.thr_after_rc = mk3(1.0f);
+        p.rs.first_dir = mk3(0.0f); p.rs.first_light_dir = mk3(0.0f);
+        p.rs.rc_pos = mk3(0.0f); p.rs.rc_normal = mk3(0.0f); p.rs.rc_incident_dir = mk3(0.0f);
+        p.rs.rc_incident_L = mk3(0.0f); p.rs.rc_nee_dir = mk3(0.0f);
+        p.rs.rc_mat_info = 0u;
+        p.rs.first_light_bsdf_pdf = 1.0f;
+        p.rs.rc_lobe = 0;
+    }
 }
 template <bool RESTIR>
 VRT_DEV void path_load_hot(const SlotRef& s, Path<RESTIR>& p) {
@@ -142,6 +155,14 @@ VRT_DEV void path_store_cold(uint32_t* line, const Path<RESTIR>& p) {
     line[PC_PPOS] = dm_f2u(p.primary_pos.x); line[PC_PPOS + 1] = dm_f2u(p.primary_pos.y); line[PC_PPOS + 2] = dm_f2u(p.primary_pos.z);
     line[PC_INVPDF] = dm_f2u(p.first_invpdf);
     line[PC_MAT] = p.primary_mat_info;
+    if constexpr (RESTIR) {
+        uint32_t* r = line + PC_RS;
+        const f3* v[8] = {&p.rs.thr_after_rc, &p.rs.first_dir, &p.rs.first_light_dir, &p.rs.rc_pos, &p.rs.rc_normal, &p.rs.rc_incident_dir,
+                          &p.rs.rc_incident_L, &p.rs.rc_nee_dir};
+#pragma unroll
+        for (int k = 0; k < 8; k++) { r[3 * k] = dm_f2u(v[k]->x); r[3 * k + 1] = dm_f2u(v[k]->y); r[3 * k + 2] = dm_f2u(v[k]->z); }
+        r[24] = p.rs.rc_mat_info; r[25] = dm_f2u(p.rs.first_light_bsdf_pdf); r[26] = (uint32_t)p.rs.rc_lobe;
+    }
 }
 template <bool RESTIR>
 VRT_DEV void path_load_cold(const uint32_t* line, Path<RESTIR>& p) {
@@ -151,6 +172,14 @@ VRT_DEV void path_load_cold(const uint32_t* line, Path<RESTIR>& p) {
     p.primary_pos = mk3(dm_u2f(line[PC_PPOS]), dm_u2f(line[PC_PPOS + 1]), dm_u2f(line[PC_PPOS + 2]));
     p.first_invpdf = dm_u2f(line[PC_INVPDF]);
     p.primary_mat_info = line[PC_MAT];
+    if constexpr (RESTIR) {
+        const uint32_t* r = line + PC_RS;
+        f3* v[8] = {&p.rs.thr_after_rc, &p.rs.first_dir, &p.rs.first_light_dir, &p.rs.rc_pos, &p.rs.rc_normal, &p.rs.rc_incident_dir,
+                    &p.rs.rc_incident_L, &p.rs.rc_nee_dir};
+#pragma unroll
+        for (int k = 0; k < 8; k++) *v[k] = mk3(dm_u2f(r[3 * k]), dm_u2f(r[3 * k + 1]), dm_u2f(r[3 * k + 2]));
+        p.rs.rc_mat_info = r[24]; p.rs.first_light_bsdf_pdf = dm_u2f(r[25]); p.rs.rc_lobe = (int)r[26];
+    }
 }
 
 // What becomes of a closest-hit ray that ended at distance t (voxel units) given the floor distance of its path
@@ -221,10 +250,10 @@ VRT_DEV int pool_begin(const FrameParams& fp, const SlotRef& s, int u, int v, in
 
 // SHADE (KIND = HIT_SOMETHING) and ESCAPE (KIND = HIT_NOTHING): rebuild the closest hit from the slot, run the
 // segment, then either set up the bounce ray or finish the path.  Returns the slot's next state.
-template <int KIND, bool BLACK_SUN, class PyrT>
+template <int KIND, bool BLACK_SUN, bool RESTIR = false, class PyrT>
 VRT_DEV int pool_shade(const FrameParams& fp, const SceneData& sc, const PyrT& P, const PixelBuffers& out, const SlotRef& s,
                        uint32_t* cold_line, TraceStats& ts) {
-    Path<false> p;
+    Path<RESTIR> p;
     path_load_hot(s, p);
     const int local_idx = (p.pix_v - fp.row0) * fp.W + p.pix_u;
     const int depth = p.depth;
@@ -239,13 +268,14 @@ VRT_DEV int pool_shade(const FrameParams& fp, const SceneData& sc, const PyrT& P
                     normal_decode(b >> 20), (int)s.u(PF_ITERS), tr);
         hit_voxel<false, PyrT::G>(fp, sc, world_to_voxel<PyrT::G>(p.pos), p.d, tr, h, ts);
     }
-    const bool done = path_shade<false, KIND, BLACK_SUN>(fp, sc, P, out, local_idx, p, h, ts);
+    if constexpr (RESTIR) { if (depth > 0) path_load_cold(cold_line, p); }  // the reconnection state is updated at every vertex
+    const bool done = path_shade<RESTIR, KIND, BLACK_SUN>(fp, sc, P, out, local_idx, p, h, ts);
     if (done) {
-        if (depth > 0) path_load_cold(cold_line, p);
-        path_finish<false>(fp, sc, out, local_idx, p, ts);
+        if constexpr (!RESTIR) { if (depth > 0) path_load_cold(cold_line, p); }
+        path_finish<RESTIR>(fp, sc, out, local_idx, p, ts);
         return SLOT_EMPTY;
     }
-    if (depth == 0) path_store_cold(cold_line, p);
+    if (RESTIR || depth == 0) path_store_cold(cold_line, p);
     path_store_hot(s, p);
     return pool_launch_ray<PyrT::G>(fp, s, p.pos, p.d, ts);
 }
