@@ -384,6 +384,14 @@ int emu_bsdf_selftest(int n, uint32_t seed) {
                 if (mode == PDF_LOBE) ok = ok && same(rp_lobe, xp);
                 if (mode == PDF_ALL) ok = ok && same(rp_all, xp);
                 if (!ok) bad++;
+                // the same with the terms that do not depend on the view vector taken from the prepare pass's helpers
+                const SurfShared cv = surf_shared_view(b, mat_colours(m), all || lobe_has(lobe, LOBE_DIFFUSE), all || lobe_has(lobe, LOBE_SPEC),
+                                                       all || lobe_has(lobe, LOBE_CLEARCOAT));
+                f3 yd, ys;
+                float yp;
+                bsdf_eval_pdf_pre(b, cv, l, dir_terms(b.n, b.tx, b.ty, b.ax, b.ay, l), lobe, mode, yd, ys, yp);
+                bool ok2 = same(yd.x, xd.x) && same(yd.y, xd.y) && same(yd.z, xd.z) && same(ys.x, xs.x) && same(ys.y, xs.y) && same(ys.z, xs.z) && same(yp, xp);
+                if (!ok2) bad++;
             }
         }
     }

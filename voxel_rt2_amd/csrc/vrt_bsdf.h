@@ -276,6 +276,93 @@ VRT_DEV void bsdf_eval_pdf(const Surf& s, const SurfShared& c, f3 l, int lobe, i
     }
 }
 
+// A reconnection vertex is evaluated ~30 times per pixel with the SAME normal, material and light directions (the sample's
+// continuation and its sun sample) and a different view vector each time.  What bsdf_eval_pdf() derives from (surface, light
+// direction) alone and from the material alone is worked out once per sample (vrt_restir.h, gris_prepare_pixel) by these
+// two helpers -- the same expressions with the same operands, so the same bits:
+struct DirTerms { float nl, fl, g_l, gc_l, pd; };   // n.l; pow5(1 - n.l); smith_aniso and smith_iso(0.25) of the light vector; saturate(n.l) / pi
+VRT_DEV DirTerms dir_terms(f3 n, f3 tx, f3 ty, float ax, float ay, f3 l) {
+    DirTerms t;
+    t.nl = dot3(n, l);
+    t.fl = dm_pow5(1.0f - t.nl);
+    t.g_l = smith_aniso(t.nl, dot3(l, tx), dot3(l, ty), ax, ay);
+    t.gc_l = smith_iso(t.nl, 0.25f);
+    t.pd = dm_saturate(t.nl) / DM_PI;
+    return t;
+}
+struct MatColours { f3 lambert, sheen_col, spec_col; };   // the material-only fields of SurfShared
+VRT_DEV MatColours mat_colours(const Material& m) {
+    MatColours c;
+    const f3 tint = tint_of(m.base);
+    c.lambert = m.base / DM_PI;
+    c.sheen_col = m.sheen * lerp3(mk3(1.0f), tint, m.sheen_tint);
+    c.spec_col = lerp3(m.specular * 0.08f * lerp3(mk3(1.0f), tint, m.specular_tint), m.base, m.metallic);
+    return c;
+}
+// surf_shared() with the material-only fields taken from `mc`: only the view-dependent ones are computed
+VRT_DEV SurfShared surf_shared_view(const Surf& s, const MatColours& mc, bool d, bool sp, bool cc) {
+    SurfShared c;
+    c.lambert = mc.lambert; c.sheen_col = mc.sheen_col; c.spec_col = mc.spec_col;
+    c.fv = d ? dm_pow5(1.0f - s.n_v) : 0.0f;
+    c.g_v = sp ? smith_aniso(s.n_v, s.v_x, s.v_y, s.ax, s.ay) : 0.0f;
+    c.gc_v = cc ? smith_iso(s.n_v, 0.25f) : 0.0f;
+    return c;
+}
+// bsdf_eval_pdf() for a direction whose DirTerms are at hand
+VRT_DEV void bsdf_eval_pdf_pre(const Surf& s, const SurfShared& c, f3 l, const DirTerms& lt, int lobe, int pdf_mode, f3& out_d, f3& out_s, float& pdf) {
+    const Material& m = s.m;
+    out_d = mk3(0.0f);
+    out_s = mk3(0.0f);
+    const float nl = lt.nl;
+    const bool front = nl > 0.0f && s.n_v > 0.0f;
+    const bool e_d = front && lobe_has(lobe, LOBE_DIFFUSE), e_s = front && lobe_has(lobe, LOBE_SPEC), e_c = front && lobe_has(lobe, LOBE_CLEARCOAT);
+    const bool p_d = pdf_mode == PDF_ALL || (pdf_mode == PDF_LOBE && lobe == LOBE_DIFFUSE);
+    const bool p_s = pdf_mode == PDF_ALL || (pdf_mode == PDF_LOBE && lobe == LOBE_SPEC);
+    const bool p_c = pdf_mode == PDF_ALL || (pdf_mode == PDF_LOBE && lobe != LOBE_DIFFUSE && lobe != LOBE_SPEC);
+    const f3 h = norm3(l + s.v);
+    const float lh = dot3(l, h), nh = dot3(s.n, h);
+    float D = 0.0f, Dc = 0.0f;
+    if (e_s || p_s) D = gtr2_aniso(nh, dot3(h, s.tx), dot3(h, s.ty), s.ax, s.ay);
+    if (e_c || p_c) Dc = gtr1(dm_abs(nh), s.cc_alpha);
+    if (e_d) {
+        float rr = 2.0f * m.roughness * sq(lh);
+        float fl = lt.fl, fv = c.fv;
+        f3 retro = c.lambert * rr * (fl + fv + fl * fv * (rr - 1.0f));
+        f3 fd = c.lambert * (1.0f - 0.5f * fl) * (1.0f - 0.5f * fv) + retro;
+        f3 sheen = c.sheen_col * dm_pow5(1.0f - lh);
+        float fss90 = lh * lh * m.roughness;
+        float fss = lerp1(1.0f, fss90, fl) * lerp1(1.0f, fss90, fv);
+        float ss = 1.25f * (fss * (1.0f / (nl + s.n_v) - 0.5f) + 0.5f);
+        f3 sub = VRT_INV_PI * ss * m.base;
+        out_d = out_d + (lerp3(fd, sub, m.subsurface) + sheen) * (1.0f - m.metallic);
+    }
+    if (e_s) {
+        float G = lt.g_l * c.g_v;
+        f3 F = lerp3(c.spec_col, mk3(1.0f), dm_pow5(1.0f - lh));
+        out_s = out_s + D * G * F;
+    }
+    if (e_c) {
+        float F = lerp1(0.04f, 1.0f, dm_pow5(1.0f - lh));
+        float G = lt.gc_l * c.gc_v;
+        out_s = out_s + mk3(m.clearcoat * Dc * F * G);
+    }
+    float pd = 0.0f, ps = 0.0f, pc = 0.0f;
+    if (p_d) pd = lt.pd;
+    if (p_s) ps = c.g_v * dm_abs(lh) * D / dm_abs(nl);
+    if (p_c) { float anh = dm_abs(nh); pc = Dc * anh / (4.0f * dot3(s.v, h)); }
+    if (pdf_mode == PDF_ALL) {
+        pdf = 0.0f;
+        pdf += pd * s.w_d;
+        pdf += ps * s.w_s;
+        pdf += pc * s.w_c;
+    } else if (pdf_mode == PDF_LOBE) {
+        pdf = p_d ? pd * s.w_d : (p_s ? ps * s.w_s : pc * s.w_c);
+        if (dm_isinf(pdf) || dm_isnan(pdf)) pdf = 1.0f;
+    } else {
+        pdf = 0.0f;
+    }
+}
+
 VRT_DEV f3 reflect3(f3 i, f3 n) { return i - 2.0f * dot3(n, i) * n; }
 VRT_DEV f3 to_world(const Surf& s, f3 m) { return m.x * s.tx + m.z * s.ty + m.y * s.n; }  // (tangent, normal, bitangent) frame
 

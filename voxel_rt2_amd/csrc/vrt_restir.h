@@ -159,8 +159,14 @@ VRT_DEV void store_mat_derived(float* mats_x, int id, const MatDerived& x) {
 // destination), `src_sky_t` the sky transmittance toward its sun sample (GrisSrc), `mats_x` the per-material-id table of
 // mat_derive().
 // `dsc` = surf_shared(ds, ...) with at least the groups of lobe src.z.lobes % 10.
+// `pre` = what the sample's reconnection vertex contributes whatever the destination (RcPre, from the prepare pass).
+struct RcPre {
+    f3 base;             // unpack_albedo(rc_mat_info)
+    MatColours col;      // mat_colours() of the reconnection vertex' material
+    DirTerms inc, nee;   // dir_terms() of rc_incident_dir and rc_nee_dir at the reconnection vertex
+};
 VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const float* mats_x, f3 dst_pos, const Surf& ds, const SurfShared& dsc,
-                          const Reservoir& src, f3 rc_ty, f3 src_sky_t, f3& out_d, f3& out_s, float& out_jac, TraceStats& ts) {
+                          const Reservoir& src, f3 rc_ty, f3 src_sky_t, const RcPre& pre, f3& out_d, f3& out_s, float& out_jac, TraceStats& ts) {
     const bool escape = near_zero3(src.z.rc_normal);
     const bool last = near_zero3(src.z.rc_incident_dir);
     const bool nee_vis = !near_zero3(src.z.rc_nee_dir);
@@ -169,20 +175,21 @@ VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const floa
     const f3 dst_normal = ds.n;
     if (dot3(dst_normal, to_rc) < 1e-5f || (!escape && dot3(src.z.rc_normal, -to_rc) < 1e-5f)) passed = 0.0f;
 
-    int rc_id;
-    const Material rc_mat = material_from_bits(sc.mats, src.z.rc_mat_info, rc_id);
+    const int rc_id = (int)(src.z.rc_mat_info & 255u);
+    Material rc_mat = load_material(sc.mats, rc_id);   // material_from_bits() with the albedo unpacked once per sample
+    rc_mat.base = pre.base;
     f3 contrib = mk3(0.0f);
     if (!escape) {
         Surf rc;
         surf_set(rc, rc_mat, load_mat_derived(mats_x, rc_id), src.z.rc_normal, -to_rc, cross3(src.z.rc_normal, rc_ty), rc_ty);
         // two directions (the path's continuation and its sun sample) with their pdfs at one vertex: bsdf_eval_pdf
         const int rl = src.z.lobes / 10;
-        const SurfShared rcc = surf_shared(rc, nee_vis || (!last && lobe_has(rl, LOBE_DIFFUSE)), nee_vis || (!last && lobe_has(rl, LOBE_SPEC)),
-                                           nee_vis || (!last && lobe_has(rl, LOBE_CLEARCOAT)));
+        const SurfShared rcc = surf_shared_view(rc, pre.col, nee_vis || (!last && lobe_has(rl, LOBE_DIFFUSE)), nee_vis || (!last && lobe_has(rl, LOBE_SPEC)),
+                                                nee_vis || (!last && lobe_has(rl, LOBE_CLEARCOAT)));
         if (!last) {
             f3 bd, bs;
             float dst_rc_pdf;
-            bsdf_eval_pdf(rc, rcc, src.z.rc_incident_dir, rl, PDF_LOBE, bd, bs, dst_rc_pdf);
+            bsdf_eval_pdf_pre(rc, rcc, src.z.rc_incident_dir, pre.inc, rl, PDF_LOBE, bd, bs, dst_rc_pdf);
             f3 rc_brdf = (bd + bs) * dm_saturate(dot3(src.z.rc_normal, src.z.rc_incident_dir));
             float lp = cone_pdf(fp.light_cos_max, dot3(fp.light_dir, src.z.rc_incident_dir));
             float w = power_heuristic(dst_rc_pdf, lp * (nee_vis ? 1.0f : 0.0f));
@@ -191,7 +198,7 @@ VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const floa
         if (nee_vis) {
             f3 bd, bs;
             float pdf_nee;
-            bsdf_eval_pdf(rc, rcc, src.z.rc_nee_dir, LOBE_ALL, PDF_ALL, bd, bs, pdf_nee);
+            bsdf_eval_pdf_pre(rc, rcc, src.z.rc_nee_dir, pre.nee, LOBE_ALL, PDF_ALL, bd, bs, pdf_nee);
             f3 nee_brdf = (bd + bs) * dm_saturate(dot3(src.z.rc_normal, src.z.rc_nee_dir));
             float w = power_heuristic(cone_pdf(fp.light_cos_max, 1.0f), pdf_nee);
             f3 sky_t = mk3(1.0f);
@@ -240,6 +247,12 @@ struct alignas(16) GrisGeo {
     f3 x1; uint32_t mat;     // primary vertex from the g-buffer depth; packed material
     f3 v; float M;           // unit vector toward the camera; the pixel's reservoir M
     f3 ty; uint32_t pad;     // bitangent of ortho_basis(n); the tangent is cross(n, ty)
+    // the pixel as the DESTINATION of a shift: its shading point never changes (own normal, material, view vector), so the
+    // whole SurfShared of it and the unpacked albedo are worked out here
+    f3 base; float fv;
+    f3 lambert; float g_v;
+    f3 sheen_col; float gc_v;
+    f3 spec_col; uint32_t pad3;
 };
 struct alignas(16) GrisSrc {
     f3 F; float M;
@@ -250,6 +263,13 @@ struct alignas(16) GrisSrc {
     f3 rc_nee_dir; uint32_t pad0;
     f3 rc_ty; uint32_t pad1;  // bitangent of ortho_basis(rc_normal)
     f3 sky_t; uint32_t pad2;  // sky transmittance toward rc_nee_dir (atmos.py:117-131): depends on the sample alone
+    // RcPre: the reconnection vertex' material colours and the terms of its two fixed light directions
+    f3 base; float inc_nl;
+    f3 lambert; float inc_fl;
+    f3 sheen_col; float inc_g;
+    f3 spec_col; float inc_gc;
+    float nee_nl, nee_fl, nee_g, nee_gc;
+    float inc_pd, nee_pd; uint32_t pad4, pad5;
 };
 
 struct GrisBuffers {
@@ -283,6 +303,15 @@ VRT_DEV void gris_prepare_pixel(const FrameParams& fp, const SceneData& sc, cons
     f3 tx;
     ortho_basis(g.n, tx, g.ty);
     g.pad = 0u;
+    {   // the pixel's own shading point as every neighbour's shift will set it up (gris_pixel, first tap loop)
+        int id;
+        const Material m = material_from_bits(sc.mats, g.mat, id);
+        Surf ds;
+        surf_set(ds, m, load_mat_derived(gb.mats_x, id), g.n, g.v, cross3(g.n, g.ty), g.ty);
+        const SurfShared c = surf_shared(ds, true, true, true);
+        g.base = m.base; g.fv = c.fv; g.lambert = c.lambert; g.g_v = c.g_v; g.sheen_col = c.sheen_col; g.gc_v = c.gc_v;
+        g.spec_col = c.spec_col; g.pad3 = 0u;
+    }
     gb.geo[idx] = g;
     GrisSrc s;
     s.F = r.z.F; s.M = r.M; s.rc_pos = r.z.rc_pos; s.weight = r.weight; s.rc_normal = r.z.rc_normal; s.jac = r.z.jac;
@@ -293,14 +322,30 @@ VRT_DEV void gris_prepare_pixel(const FrameParams& fp, const SceneData& sc, cons
     // (pathtracer.py:770-772): one table lookup here instead of one per shift (~60 per pixel)
     s.sky_t = (fp.use_sky == 1 && !near_zero3(r.z.rc_nee_dir)) ? sky_transmittance(sc.sky, r.z.rc_nee_dir) : mk3(1.0f);
     s.pad2 = 0u;
+    {   // the reconnection vertex as shift_sample() sets it up, minus the view vector
+        int id;
+        const Material m = material_from_bits(sc.mats, r.z.rc_mat_info, id);
+        const MatDerived x = load_mat_derived(gb.mats_x, id);
+        const MatColours mc = mat_colours(m);
+        const f3 rtx = cross3(r.z.rc_normal, s.rc_ty);
+        const DirTerms a = dir_terms(r.z.rc_normal, rtx, s.rc_ty, x.ax, x.ay, r.z.rc_incident_dir);
+        const DirTerms b = dir_terms(r.z.rc_normal, rtx, s.rc_ty, x.ax, x.ay, r.z.rc_nee_dir);
+        s.base = m.base; s.lambert = mc.lambert; s.sheen_col = mc.sheen_col; s.spec_col = mc.spec_col;
+        s.inc_nl = a.nl; s.inc_fl = a.fl; s.inc_g = a.g_l; s.inc_gc = a.gc_l; s.inc_pd = a.pd;
+        s.nee_nl = b.nl; s.nee_fl = b.fl; s.nee_g = b.g_l; s.nee_gc = b.gc_l; s.nee_pd = b.pd;
+        s.pad4 = 0u; s.pad5 = 0u;
+    }
     gb.src[idx] = s;
 }
-VRT_DEV void gris_load_src(Reservoir& r, f3& rc_ty, f3& sky_t, const GrisSrc& s) {
+VRT_DEV void gris_load_src(Reservoir& r, f3& rc_ty, f3& sky_t, RcPre& pre, const GrisSrc& s) {
     r.z.F = s.F; r.M = s.M; r.z.rc_pos = s.rc_pos; r.weight = s.weight; r.z.rc_normal = s.rc_normal; r.z.jac = s.jac;
     r.z.rc_incident_dir = s.rc_incident_dir; r.z.lobes = s.lobes; r.z.rc_incident_L = s.rc_incident_L;
     r.z.rc_mat_info = s.rc_mat_info; r.z.rc_nee_dir = s.rc_nee_dir;
     rc_ty = s.rc_ty;
     sky_t = s.sky_t;
+    pre.base = s.base; pre.col.lambert = s.lambert; pre.col.sheen_col = s.sheen_col; pre.col.spec_col = s.spec_col;
+    pre.inc.nl = s.inc_nl; pre.inc.fl = s.inc_fl; pre.inc.g_l = s.inc_g; pre.inc.gc_l = s.inc_gc; pre.inc.pd = s.inc_pd;
+    pre.nee.nl = s.nee_nl; pre.nee.fl = s.nee_fl; pre.nee.g_l = s.nee_g; pre.nee.gc_l = s.nee_gc; pre.nee.pd = s.nee_pd;
 }
 
 // pathtracer.py:876-891: the taps lie on a golden-angle spiral whose phase is hashed from the pixel's 8x8 tile (pass 0),
@@ -353,7 +398,8 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
 
     Reservoir center, outr;
     f3 center_rc_ty, center_sky_t;
-    gris_load_src(center, center_rc_ty, center_sky_t, gb.src[idx]);
+    RcPre center_pre;
+    gris_load_src(center, center_rc_ty, center_sky_t, center_pre, gb.src[idx]);
     reservoir_init(outr);
 
     const GrisGeo cg = gb.geo[idx];
@@ -401,14 +447,16 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         const int tx = u + (packed & 255) - 128, ty = v + (packed >> 8) - 128;
         const GrisGeo ng = gb.geo[(ty - fp.row0) * fp.W + tx];
         const float nb_M = ng.M;
-        int nmat_id;
-        const Material nmat = material_from_bits(sc.mats, ng.mat, nmat_id);
+        const int nmat_id = (int)(ng.mat & 255u);
+        Material nmat = load_material(sc.mats, nmat_id);
+        nmat.base = ng.base;
         f3 cd, cs;
         float cjac;
         Surf nds;
         surf_set(nds, nmat, load_mat_derived(gb.mats_x, nmat_id), ng.n, ng.v, cross3(ng.n, ng.ty), ng.ty);
-        const SurfShared ndsc = surf_shared(nds, lobe_has(cl, LOBE_DIFFUSE), lobe_has(cl, LOBE_SPEC), lobe_has(cl, LOBE_CLEARCOAT));
-        shift_sample(fp, sc, gb.mats_x, ng.x1, nds, ndsc, center, center_rc_ty, center_sky_t, cd, cs, cjac, ts);
+        SurfShared ndsc;   // the neighbour's own shading point: all of it from the prepare pass
+        ndsc.lambert = ng.lambert; ndsc.sheen_col = ng.sheen_col; ndsc.spec_col = ng.spec_col; ndsc.fv = ng.fv; ndsc.g_v = ng.g_v; ndsc.gc_v = ng.gc_v;
+        shift_sample(fp, sc, gb.mats_x, ng.x1, nds, ndsc, center, center_rc_ty, center_sky_t, center_pre, cd, cs, cjac, ts);
         float c_p_hat = lum(cd + cs) * cjac;
         float cw = c_p_hat * nb_M;
         cw /= c_p_hat * nb_M + lum(center.z.F) * center.M / (float)max_taps;
@@ -420,10 +468,11 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         const int tx = u + (packed & 255) - 128, ty = v + (packed >> 8) - 128;
         Reservoir nb;
         f3 nb_rc_ty, nb_sky_t;
-        gris_load_src(nb, nb_rc_ty, nb_sky_t, gb.src[(ty - fp.row0) * fp.W + tx]);
+        RcPre nb_pre;
+        gris_load_src(nb, nb_rc_ty, nb_sky_t, nb_pre, gb.src[(ty - fp.row0) * fp.W + tx]);
         f3 sd, ss;
         float jac;
-        shift_sample(fp, sc, gb.mats_x, cx1, cds, cdsc, nb, nb_rc_ty, nb_sky_t, sd, ss, jac, ts);
+        shift_sample(fp, sc, gb.mats_x, cx1, cds, cdsc, nb, nb_rc_ty, nb_sky_t, nb_pre, sd, ss, jac, ts);
 
         float p_hat = lum(sd + ss);
         float p_hat_n = p_hat / jac;
