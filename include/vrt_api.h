@@ -127,6 +127,14 @@ int vrt_prepare(vrt_ctx* ctx);
 /* Renderer.accumulate_clouds / compute_atmosphere (pathtracer.py:325-329) */
 int vrt_sky_accumulate_clouds(vrt_ctx* ctx, int max_samples);
 int vrt_sky_compute_slice(vrt_ctx* ctx, int slice_idx, int max_slices);
+/* The same precompute split across GPUs (the reference already slices the atmosphere pass by table columns,
+ * atmos.py:159-164, scene.py:243-253): one cloud pass (atmos.py:140-157) over the columns of ONE slice, and the copy of table
+ * columns between the library's tables and caller-owned device memory that an all-gather needs.  A texel depends on no other
+ * texel in either pass, so a rank that owns slice r runs the cloud passes and the atmosphere pass on slice r only and the
+ * ranks exchange columns: voxel_rt2_amd/parallel.py, precompute_sky_sharded(). */
+int vrt_sky_accumulate_clouds_slice(vrt_ctx* ctx, int max_samples, int slice_idx, int max_slices);
+int vrt_sky_table_io(vrt_ctx* ctx, int which /* VRT_BUF_SKY_SCATTERING | VRT_BUF_SKY_TRANSMITTANCE */, int u0, int u1,
+                     void* device_ptr /* f32[u1-u0][sky_res][3] */, int to_library);
 /* Renderer.accumulate (pathtracer.py:1310-1319), n_samples times */
 int vrt_accumulate(vrt_ctx* ctx, int n_samples);
 /* Renderer.reset_framebuffer (pathtracer.py:664-668) / copy_prev_matrices (283-287) */

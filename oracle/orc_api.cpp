@@ -92,6 +92,20 @@ int orc_set_camera(orc_ctx* c, const vrt_camera* cam) {
 int orc_prepare(orc_ctx* c) { c->r.prepare_data(); return 0; }
 int orc_sky_accumulate_clouds(orc_ctx* c, int max_samples) { c->r.accumulate_clouds(max_samples); return 0; }
 int orc_sky_compute_slice(orc_ctx* c, int slice, int max_slices) { c->r.compute_atmosphere(slice, max_slices); return 0; }
+/* the two entry points of the sharded precompute (include/vrt_api.h), on host memory */
+int orc_sky_accumulate_clouds_slice(orc_ctx* c, int max_samples, int slice, int max_slices) {
+    c->r.accumulate_clouds_slice(max_samples, slice, max_slices);
+    return 0;
+}
+int orc_sky_table_io(orc_ctx* c, int which, int u0, int u1, void* ptr, int to_library) {
+    Atmos& a = c->r.atmos;
+    if (which != VRT_BUF_SKY_SCATTERING && which != VRT_BUF_SKY_TRANSMITTANCE) return -1;
+    if (u0 < 0 || u1 > a.res || u1 <= u0) return -1;
+    V3* table = (which == VRT_BUF_SKY_SCATTERING ? a.skybox_scattering.data() : a.skybox_transmittance.data()) + (size_t)u0 * a.res;
+    size_t bytes = (size_t)(u1 - u0) * a.res * sizeof(V3);
+    if (to_library) memcpy(table, ptr, bytes); else memcpy(ptr, table, bytes);
+    return 0;
+}
 int orc_accumulate(orc_ctx* c, int n) {
     for (int i = 0; i < n; i++) c->r.accumulate();
     return 0;

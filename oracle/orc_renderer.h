@@ -158,6 +158,16 @@ struct Renderer {
         stats = dummy;
         atmos.cloud_pass++;
     }
+    /* one cloud pass over the columns of one slice (a texel's passes depend on no other texel: atmos.py:140-157) */
+    void accumulate_clouds_slice(int max_samples, int slice_idx, int max_slices) {
+        int w = atmos.res / max_slices;
+        Stats dummy = stats;
+        parallel_rows(w * slice_idx, w * (slice_idx + 1), [&](int a, int b, Stats*) {
+            atmos.accumulate_clouds_rows(light_direction, light_color * light_weight, light_cone_cos_theta_max, max_samples, a, b);
+        });
+        stats = dummy;
+        atmos.cloud_pass++;
+    }
     void compute_atmosphere(int slice_idx, int max_slices) {
         int slice_width = atmos.res / max_slices; /* atmos.py:162 */
         Stats dummy = stats;

@@ -75,3 +75,53 @@ def test_split_rows_covers_frame():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(n - 1))
             assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
     assert parallel.split_rows(1080, 8)[3] == (405, 540)  # 135-row tiles at 1080p
+
+
+# ---- sky precompute split by table columns ---------------------------------------------------------------------
+SKY_R = 32
+
+
+def _sky_worker(rank, world, port, out_path):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import orc
+    from voxel_rt2_amd import _abi, host, scenes, parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mat, rgb, params = scenes.scene_s6(0)
+    cfg = host.make_config(48, 32, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=3, seed=4, sky_res=SKY_R)
+    o = orc.Oracle(cfg, threads=1)
+    orc.setup(o, mat, rgb, params, cloud=_cloud_tile())
+    parallel.precompute_sky_sharded(o, rank, world, device="cpu", cloud_passes=3, cloud_samples=3, atmosphere_slices=4)
+    if rank == world - 1:   # any rank holds the full tables afterwards
+        np.save(out_path, np.stack([o.fetch_buffer(_abi.BUF_SKY_SCATTERING), o.fetch_buffer(_abi.BUF_SKY_TRANSMITTANCE)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _cloud_tile():
+    x = np.arange(256)
+    t = (np.sin(x[:, None] * 0.11) * np.cos(x[None, :] * 0.07) * 0.5 + 0.5) * 255
+    return np.stack([t, t.T, np.full_like(t, 230)], axis=-1).astype(np.uint8)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sky_precompute_sharded_by_columns_equals_unsharded(tmp_path, world):
+    import orc
+    from voxel_rt2_amd import _abi, host, scenes
+    out = str(tmp_path / "sky.npy")
+    mp.spawn(_sky_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    mat, rgb, params = scenes.scene_s6(0)
+    cfg = host.make_config(48, 32, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=3, seed=4, sky_res=SKY_R)
+    o = orc.Oracle(cfg, threads=2)
+    orc.setup(o, mat, rgb, params, cloud=_cloud_tile())
+    for _ in range(3):
+        o.sky_accumulate_clouds(3)
+    for sl in range(4):
+        o.sky_compute_slice(sl, 4)
+    ref = np.stack([o.fetch_buffer(_abi.BUF_SKY_SCATTERING), o.fetch_buffer(_abi.BUF_SKY_TRANSMITTANCE)])
+    assert np.isfinite(ref).all() and ref[0].max() > 0 and ref[1].max() > 0
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

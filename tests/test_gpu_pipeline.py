@@ -179,3 +179,47 @@ def test_rccl_beside_the_library():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out == dict(same=True, backend="nccl", queues="8")
+
+
+def test_sky_precompute_split_by_columns_on_the_gpu():
+    """The sharded sky precompute (parallel.precompute_sky_columns + vrt_sky_table_io) with three "ranks" played by three
+    contexts on the one GPU, columns exchanged through device tensors: every context ends with the tables of an unsharded
+    precompute, bit for bit (the collective itself is covered on CPU by tests/test_dist_gloo.py)."""
+    import torch
+    from voxel_rt2_amd import _abi, parallel
+    R, world = 96, 3
+    mat, rgb, params = scenes.scene_s6(0)
+    cloud = np.load(os.path.join(ROOT, "voxel_rt2_amd", "data", "cloud_texture.npy"))
+    cfg = host.make_config(64, 40, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=3, seed=4, sky_res=R)
+
+    def context():
+        s = NativeSession(_lib.load(), "vrt_", cfg)
+        orc.setup(s, mat, rgb, params, cloud=cloud)
+        return s
+
+    ref = context()
+    for _ in range(4):
+        ref.sky_accumulate_clouds(4)
+    for sl in range(6):
+        ref.sky_compute_slice(sl, 6)
+    want = [ref.fetch_buffer(_abi.BUF_SKY_SCATTERING), ref.fetch_buffer(_abi.BUF_SKY_TRANSMITTANCE)]
+    assert np.isfinite(want[0]).all() and want[0].max() > 0
+    ranks = [context() for _ in range(world)]
+    for r, s in enumerate(ranks):
+        parallel.precompute_sky_columns(s, r, world, cloud_passes=4, cloud_samples=4, atmosphere_slices=6)
+    w = R // world
+    for k, which in enumerate((_abi.BUF_SKY_SCATTERING, _abi.BUF_SKY_TRANSMITTANCE)):
+        full = torch.empty((world, w, R, 3), dtype=torch.float32, device="cuda")
+        for r, s in enumerate(ranks):   # "all-gather"
+            s.sky_table_io(which, r * w, (r + 1) * w, full[r].data_ptr(), False)
+            s.sync()
+        for r, s in enumerate(ranks):
+            for q in range(world):
+                if q != r:
+                    s.sky_table_io(which, q * w, (q + 1) * w, full[q].data_ptr(), True)
+            s.sync()
+            assert np.array_equal(s.fetch_buffer(which).view(np.uint32), want[k].view(np.uint32)), (which, r)
+    # and a frame rendered from the exchanged tables equals one rendered from the unsharded ones
+    for s in (ref, ranks[1]):
+        s.accumulate(2)
+    assert np.array_equal(ref.fetch_hdr().view(np.uint32), ranks[1].fetch_hdr().view(np.uint32))

@@ -68,6 +68,8 @@ def declare(lib, prefix):
     sig("prepare", C.c_int, P)
     sig("sky_accumulate_clouds", C.c_int, P, C.c_int)
     sig("sky_compute_slice", C.c_int, P, C.c_int, C.c_int)
+    sig("sky_accumulate_clouds_slice", C.c_int, P, C.c_int, C.c_int, C.c_int)
+    sig("sky_table_io", C.c_int, P, C.c_int, C.c_int, C.c_int, P, C.c_int)
     sig("accumulate", C.c_int, P, C.c_int)
     sig("reset", C.c_int, P)
     sig("end_frame", C.c_int, P)

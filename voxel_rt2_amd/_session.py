@@ -89,6 +89,13 @@ class NativeSession:
     def sky_compute_slice(self, slice_idx, max_slices):
         self._call("sky_compute_slice", int(slice_idx), int(max_slices))
 
+    def sky_accumulate_clouds_slice(self, max_samples, slice_idx, max_slices):
+        self._call("sky_accumulate_clouds_slice", int(max_samples), int(slice_idx), int(max_slices))
+
+    def sky_table_io(self, which, u0, u1, ptr, to_library):
+        """Columns [u0, u1) of a sky table <-> caller memory at `ptr` (device memory for the HIP library, host for the oracle)."""
+        self._call("sky_table_io", int(which), int(u0), int(u1), C.c_void_p(int(ptr)), int(bool(to_library)))
+
     def accumulate(self, n=1):
         self._call("accumulate", int(n))
 

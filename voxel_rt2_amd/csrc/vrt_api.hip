@@ -448,8 +448,42 @@ int vrt_sky_accumulate_clouds(vrt_ctx* c, int max_samples) {
     float cm;
     sun_of(c, sd, sc_, cm);
     c->main_dirty = true;
-    HIP_TRY(launch_sky_clouds(c->stream, make_sky(c), sd, sc_, cm, max_samples, c->cloud_pass));
+    HIP_TRY(launch_sky_clouds(c->stream, make_sky(c), sd, sc_, cm, max_samples, c->cloud_pass, 0, c->cfg.sky_res));
     c->cloud_pass++;
+    return VRT_OK;
+}
+// One cloud pass over the table columns of slice `slice_idx` of `max_slices` only (the split of vrt_sky_compute_slice,
+// atmos.py:162).  A texel's passes depend on no other texel, so ranks that each own a slice run this max_samples times,
+// then vrt_sky_compute_slice on their slice, and exchange columns (vrt_sky_table_io): voxel_rt2_amd/parallel.py.
+int vrt_sky_accumulate_clouds_slice(vrt_ctx* c, int max_samples, int slice_idx, int max_slices) {
+    if (!c || max_samples <= 0 || max_slices <= 0 || slice_idx < 0 || slice_idx >= max_slices) return fail(VRT_E_INVALID, "bad argument");
+    if (!c->prepared || c->scene.use_physical_sky != 1) return fail(VRT_E_STATE, "needs vrt_prepare with use_physical_sky");
+    HIP_TRY(hipSetDevice(c->device));
+    f3 sd, sc_;
+    float cm;
+    sun_of(c, sd, sc_, cm);
+    const int w = c->cfg.sky_res / max_slices;
+    c->main_dirty = true;
+    HIP_TRY(launch_sky_clouds(c->stream, make_sky(c), sd, sc_, cm, max_samples, c->cloud_pass, w * slice_idx, w * (slice_idx + 1)));
+    c->cloud_pass++;
+    return VRT_OK;
+}
+// Copy table columns [u0, u1) between the library's sky tables and caller-owned DEVICE memory (f32[u1-u0][R][3], the table's
+// own layout: a column slice is one contiguous block).  which = VRT_BUF_SKY_SCATTERING / VRT_BUF_SKY_TRANSMITTANCE;
+// to_library = 0 reads, 1 writes.  Queued on the context's stream.
+int vrt_sky_table_io(vrt_ctx* c, int which, int u0, int u1, void* device_ptr, int to_library) {
+    if (!c || !device_ptr) return fail(VRT_E_INVALID, "null argument");
+    if (c->cfg.sky_res <= 0) return fail(VRT_E_STATE, "no sky tables");
+    if (which != VRT_BUF_SKY_SCATTERING && which != VRT_BUF_SKY_TRANSMITTANCE) return fail(VRT_E_INVALID, "not a sky table");
+    if (u0 < 0 || u1 > c->cfg.sky_res || u1 <= u0) return fail(VRT_E_INVALID, "column range outside the table");
+    HIP_TRY(hipSetDevice(c->device));
+    float* table = which == VRT_BUF_SKY_SCATTERING ? c->d_sky_scat : c->d_sky_trans;
+    const size_t col = (size_t)c->cfg.sky_res * 3 * sizeof(float);
+    char* lib = (char*)table + (size_t)u0 * col;
+    const size_t bytes = (size_t)(u1 - u0) * col;
+    c->main_dirty = true;
+    if (to_library) HIP_TRY(hipMemcpyAsync(lib, device_ptr, bytes, hipMemcpyDeviceToDevice, c->stream));
+    else HIP_TRY(hipMemcpyAsync(device_ptr, lib, bytes, hipMemcpyDeviceToDevice, c->stream));
     return VRT_OK;
 }
 int vrt_sky_compute_slice(vrt_ctx* c, int slice_idx, int max_slices) {

@@ -69,7 +69,7 @@ struct SkyPrecompute {
 };
 hipError_t launch_sky_prepare(hipStream_t st, const SkyPrecompute& sp, f3 sun_dir, f3 sun_col, float sun_cos);
 hipError_t launch_sky_clouds(hipStream_t st, const SkyPrecompute& sp, f3 sun_dir, f3 sun_col, float sun_cos, int max_samples,
-                             uint32_t pass);
+                             uint32_t pass, int u0, int u1);   // table columns [u0, u1)
 hipError_t launch_sky_slice(hipStream_t st, const SkyPrecompute& sp, f3 sun_dir, f3 sun_col, float sun_cos, int u0, int u1);
 
 }  // namespace vrt

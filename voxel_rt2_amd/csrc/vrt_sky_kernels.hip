@@ -219,10 +219,10 @@ __device__ __forceinline__ float cloud_phase(float ct, float an) {  // atmos.py:
 }
 
 // atmos.py:140-157 + 269-349
-__global__ __launch_bounds__(256) void k_sky_clouds(SkyPrecompute sp, f3 sun_dir, f3 sun_col, float sun_cos, int max_samples, uint32_t pass) {
+__global__ __launch_bounds__(256) void k_sky_clouds(SkyPrecompute sp, f3 sun_dir, f3 sun_col, float sun_cos, int max_samples, uint32_t pass, int u0, int u1) {
     const int v = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int u = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (u >= sp.res || v >= sp.res) return;
+    const int u = u0 + blockIdx.y * 4 + (threadIdx.x >> 6);   // columns [u0, u1): a texel depends on no other (atmos.py:140-157)
+    if (u >= u1 || v >= sp.res) return;
     const SunArgs sun = make_sun(sun_dir, sun_col, sun_cos);
     const f3 ambient = mk3(sp.cloud_ambient[0], sp.cloud_ambient[1], sp.cloud_ambient[2]);
     dm_rng rng = dm_rng_init(sp.seed, pass, (uint32_t)(u * sp.res + v), 2u);
@@ -329,9 +329,10 @@ hipError_t launch_sky_prepare(hipStream_t st, const SkyPrecompute& sp, f3 sun_di
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_sky_clouds(hipStream_t st, const SkyPrecompute& sp, f3 sun_dir, f3 sun_col, float sun_cos, int max_samples, uint32_t pass) {
-    dim3 g((sp.res + 63) / 64, (sp.res + 3) / 4), b(256);
-    hipLaunchKernelGGL(k_sky_clouds, g, b, 0, st, sp, sun_dir, sun_col, sun_cos, max_samples, pass);
+hipError_t launch_sky_clouds(hipStream_t st, const SkyPrecompute& sp, f3 sun_dir, f3 sun_col, float sun_cos, int max_samples, uint32_t pass, int u0, int u1) {
+    if (u1 <= u0) return hipSuccess;
+    dim3 g((sp.res + 63) / 64, (u1 - u0 + 3) / 4), b(256);
+    hipLaunchKernelGGL(k_sky_clouds, g, b, 0, st, sp, sun_dir, sun_col, sun_cos, max_samples, pass, u0, u1);
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
