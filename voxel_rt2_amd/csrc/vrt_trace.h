@@ -39,7 +39,7 @@ VRT_DEV unsigned long long brick_sub(int cx, int cy, int cz) {  // the 2x2x2 blo
 // in l0 word order -- so that the hits of neighbouring pixels, which land on neighbouring voxels of a surface, share lines.
 template <int G>
 VRT_DEV int texel_index(int x, int y, int z) {
-    if (G == 128) return ((x << 7) | y) << 7 | z;
+    if (G == 128) return ((x << 7) | y) << 7 | z;   // (brick-tiled at 128^3 as well: measured no difference, the 8 MiB stay cached)
     return (((((z >> 2) << 6) | (y >> 2)) << 6 | (x >> 2)) << 6) | brick_bit(x, y, z);
 }
 
