@@ -25,6 +25,7 @@ struct Emu {
     std::vector<uint32_t> grid;
     std::vector<unsigned long long> l0, l1, l2, l3, l0c;
     std::vector<uint32_t> l0c_base;  // [512] + count
+    float cull[16];                  // k_cull_box's grown box + flag, then the same with the flag off
     std::vector<float> mats, mats_x, sky_scat, sky_trans;
     std::vector<GrisGeo> gris_geo;
     std::vector<GrisSrc> gris_src;
@@ -126,6 +127,21 @@ int emu_upload_voxels(Emu* c, const int8_t* mat, const uint8_t* rgb) {
             out[b] = w;
         }
     };
+    {   // k_cull_box
+        int lo[3] = {1 << 20, 1 << 20, 1 << 20}, hi[3] = {-(1 << 20), -(1 << 20), -(1 << 20)};
+        for (int b = 0; b < n0 * n0 * n0; b++) {
+            if (c->l0[b] == 0ULL) continue;
+            const int cc[3] = {b % n0, (b / n0) % n0, b / (n0 * n0)};
+            for (int a = 0; a < 3; a++) { lo[a] = lo[a] < cc[a] * 4 ? lo[a] : cc[a] * 4; hi[a] = hi[a] > cc[a] * 4 + 4 ? hi[a] : cc[a] * 4 + 4; }
+        }
+        bool some = false;
+        for (int a = 0; a < 3; a++) {
+            c->cull[a] = (float)lo[a] - VRT_CULL_MARGIN; c->cull[3 + a] = (float)hi[a] + VRT_CULL_MARGIN;
+            c->cull[8 + a] = -1e30f; c->cull[11 + a] = 1e30f;
+            some = some || c->cull[a] > 0.0f || c->cull[3 + a] < (float)G;
+        }
+        c->cull[6] = some ? 1.0f : 0.0f; c->cull[7] = 0.0f; c->cull[14] = 0.0f; c->cull[15] = 0.0f;
+    }
     coarse(c->l0, c->l1, G / 16);
     coarse(c->l1, c->l2, G / 64);
     c->l0c.assign(32768, 0ULL);
@@ -189,7 +205,7 @@ static void render_all_pool(Emu* c, const FrameParams& fp, const SceneData& sc, 
             if (outside_render_area(fp, (float)u, (float)v)) continue;
             uint32_t slot[PF_COUNT] = {0}, cold[ColdLine<RESTIR>::count] = {0};
             SlotRef s{slot, 1};
-            int st = pool_begin<G>(fp, s, u, v, 0, c->ts);
+            int st = pool_begin<G>(fp, sc.cull, s, u, v, 0, c->ts);
             while (st != SLOT_EMPTY) {
                 if (st == SLOT_RAY) {
                     RayWalk w;
@@ -230,6 +246,7 @@ static int accumulate_g(Emu* c, int n_samples) {
         sc.sky.scattering = c->sky_scat.data(); sc.sky.transmittance = c->sky_trans.data();
         sc.sky.res = c->cfg.sky_res; sc.sky.fres = c->cfg.sky_res > 0 ? (float)(1.0 / (double)c->cfg.sky_res) : 0.0f;
         sc.counters = nullptr;
+        sc.cull = c->cull + (getenv("VRT_EMU_CULL") ? 0 : 8);   // off by default: the CPU tests compare traversal counters with the oracle's
         PixelBuffers out;
         f3* rt = c->cbuf[c->cidx].data();
         f3* hdr = c->cbuf[c->cidx ^ 1].data();

@@ -14,15 +14,26 @@ BUFS = (_abi.BUF_GBUF_DEPTH, _abi.BUF_GBUF_NORMAL, _abi.BUF_GBUF_POSITION, _abi.
         _abi.BUF_HISTORY_DIFFUSE, _abi.BUF_HISTORY_SPECULAR)
 
 
-@pytest.fixture(autouse=True, params=["fused", "pool"])
+@pytest.fixture(autouse=True, params=["fused", "pool", "fused+cull", "pool+cull"])
 def render_schedule(request, monkeypatch):
     """Both schedules of the render stage: path_segment per pixel (vrt_path.h) and the pooled kernel's stage
-    functions stepped through their packed LDS slot, walks suspended and resumed every third step (vrt_pool.h)."""
-    if request.param == "pool":
+    functions stepped through their packed LDS slot, walks suspended and resumed every third step (vrt_pool.h) -- each
+    with and without the culling of rays that cannot hit a voxel (cull_ray, vrt_trace.h: the shipped kernels cull; with
+    it on, rays / steps / queries are no longer the reference's, so only the images are compared)."""
+    if request.param.startswith("pool"):
         monkeypatch.setenv("VRT_EMU_POOL", "1")
     else:
         monkeypatch.delenv("VRT_EMU_POOL", raising=False)
+    if request.param.endswith("+cull"):
+        monkeypatch.setenv("VRT_EMU_CULL", "1")
+    else:
+        monkeypatch.delenv("VRT_EMU_CULL", raising=False)
     return request.param
+
+
+def culling():
+    import os
+    return bool(os.environ.get("VRT_EMU_CULL"))
 
 
 def pair(scene, W, H, depth, seed, restir=False, rows=None):
@@ -41,7 +52,7 @@ def assert_same(o, e, stats=True):
     for which in BUFS:
         x, y = o.fetch_buffer(which), e.fetch_buffer(which)
         assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), f"buffer {which}"
-    if stats:
+    if stats and not culling():
         so, se = o.stats(), e.stats()
         for k in ("rays", "dda_iters", "occupancy_queries", "closest_hits", "sky_lookups"):
             assert so[k] == se[k], k
@@ -64,6 +75,8 @@ def test_render_and_temporal(scene, W, H, depth, spp):
     assert_same(o, e, stats=sun_on)
     if not sun_on:
         assert e.stats()["rays"] < o.stats()["rays"]
+    if culling():
+        assert e.stats()["dda_iters"] <= o.stats()["dda_iters"] and (scene == "dense" or e.stats()["dda_iters"] < o.stats()["dda_iters"])
 
 
 def test_restir():

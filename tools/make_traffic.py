@@ -57,7 +57,8 @@ def main():
         name, d = arg.split("=", 1)
         m = kernel_means(d)
         ent = {}
-        for short, prefix, ia in (("k_render_pool", "vrt::k_render_pool<", 1), ("k_render", "vrt::k_render<", 2), ("k_gris", "vrt::k_gris<", 1),
+        for short, prefix, ia in (("k_render_pool", "vrt::k_render_pool<", 1), ("k_render_pool_restir", "vrt::k_render_pool_restir<", 1),
+                                  ("k_render", "vrt::k_render<", 2), ("k_gris", "vrt::k_gris<", 1),
                                   ("k_gris_prepare", "vrt::k_gris_prepare", None), ("k_temporal", "vrt::k_temporal", None)):
             k, v = pick(m, prefix, ia)
             if v:

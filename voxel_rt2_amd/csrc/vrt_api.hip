@@ -55,6 +55,8 @@ struct vrt_ctx {
     int8_t* d_mat = nullptr; uint8_t* d_rgb = nullptr; uint32_t* d_grid = nullptr;
     unsigned long long *d_l0 = nullptr, *d_l1 = nullptr, *d_l2 = nullptr, *d_l3 = nullptr, *d_l0c = nullptr;
     uint32_t* d_l0c_base = nullptr;  // [512] offsets + [1] count
+    bool cull_active = false;        // the grown box leaves part of the grid out: there are rays to cull (read back by vrt_prepare)
+    float* d_cull = nullptr;         // [8] grown bounding box of the solid voxels + flag, [8] the same with the flag off (cull_ray, vrt_trace.h)
     float* d_mats = nullptr;
     Counters* d_counters = nullptr;
     unsigned* d_work = nullptr;
@@ -221,6 +223,12 @@ static FrameParams make_frame_params(const vrt_ctx* c) {
     fp.frame = c->frame;
     return fp;
 }
+// launches that count the reference's work walk every ray, as the reference and the oracle do; VRT_CULL=0 for A/B runs
+static bool culling(const vrt_ctx* c) {
+    bool cull = c->cull_active && !(c->instrumented && !c->count_as_timed);
+    if (const char* e = getenv("VRT_CULL")) cull = cull && atoi(e) != 0;
+    return cull;
+}
 static SceneData make_scene_data(const vrt_ctx* c) {
     SceneData sc;
     sc.pyr.l0 = c->d_l0; sc.pyr.l1 = c->d_l1; sc.pyr.l2 = c->d_l2; sc.pyr.l3 = c->d_l3;
@@ -232,6 +240,7 @@ static SceneData make_scene_data(const vrt_ctx* c) {
     sc.sky.res = c->cfg.sky_res;
     sc.sky.fres = c->cfg.sky_res > 0 ? (float)(1.0 / (double)c->cfg.sky_res) : 0.0f;
     sc.counters = c->d_counters;
+    sc.cull = c->d_cull + (culling(c) ? 0 : 8);
     return sc;
 }
 static SkyPrecompute make_sky(const vrt_ctx* c) {
@@ -296,7 +305,7 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
     const size_t nw0 = nvox / 64, nw1 = nw0 / 64, nw2 = nw1 / 64;  // words of the brick levels
     ok = ok && dalloc(&c->d_mat, nvox) == hipSuccess && dalloc(&c->d_rgb, nvox * 3) == hipSuccess && dalloc(&c->d_grid, nvox) == hipSuccess;
     ok = ok && dalloc(&c->d_l0, nw0) == hipSuccess && dalloc(&c->d_l1, nw1) == hipSuccess && dalloc(&c->d_l2, nw2) == hipSuccess &&
-         dalloc(&c->d_l3, 1) == hipSuccess && dalloc(&c->d_l0c, 32768) == hipSuccess && dalloc(&c->d_l0c_base, 513) == hipSuccess;
+         dalloc(&c->d_l3, 1) == hipSuccess && dalloc(&c->d_cull, 16) == hipSuccess && dalloc(&c->d_l0c, 32768) == hipSuccess && dalloc(&c->d_l0c_base, 513) == hipSuccess;
     ok = ok && dalloc(&c->d_mats, 128 * 14) == hipSuccess && dalloc(&c->d_counters, 1) == hipSuccess && dalloc(&c->d_work, 4 * VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE) == hipSuccess;
     ok = ok && dalloc(&c->d_cbuf[0], n) == hipSuccess && dalloc(&c->d_cbuf[1], n) == hipSuccess && dalloc(&c->d_spec_planes, n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->d_gb_pos, n) == hipSuccess;
     ok = ok && dalloc(&c->d_gb_mat, n) == hipSuccess && dalloc(&c->d_refl_planes, n * VRT_MAX_FUSED) == hipSuccess;
@@ -353,7 +362,7 @@ void vrt_destroy(vrt_ctx* c) {
     void* ptrs[] = {c->d_prim_cache[0], c->d_prim_cache[1], c->alt_multi_d[0], c->alt_spec_planes[0], c->alt_refl_planes[0], c->alt_gb_pos[0], c->alt_gb_mat[0],
                     c->alt_multi_d[1], c->alt_spec_planes[1], c->alt_refl_planes[1], c->alt_gb_pos[1], c->alt_gb_mat[1],
                     c->alt_pool_scratch, c->d_gb_normal[2], c->d_gb_depth[2], c->d_gb_normal[3], c->d_gb_depth[3],
-                    c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l3, c->d_l0c, c->d_l0c_base, c->d_mats, c->d_counters, c->d_work, c->d_sky_scat,
+                    c->d_cull, c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l3, c->d_l0c, c->d_l0c_base, c->d_mats, c->d_counters, c->d_work, c->d_sky_scat,
                     c->d_sky_trans, c->d_cloud_ambient, c->d_trans_lut, c->d_cloud_tex, c->d_cbuf[0], c->d_cbuf[1], c->d_spec_planes, c->d_color_d2,
                     c->d_color_s2, c->d_gb_pos, c->d_gb_normal[0], c->d_gb_normal[1], c->d_gb_depth[0], c->d_gb_depth[1],
                     c->d_gb_mat, c->d_refl_planes, c->d_gb_refl_f, c->d_hist_d[0], c->d_hist_d[1], c->d_hist_s[0], c->d_hist_s[1],
@@ -425,7 +434,15 @@ int vrt_prepare(vrt_ctx* c) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     c->main_dirty = true;
-    HIP_TRY(launch_prepare(c->stream, c->cfg.grid_res, c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l3, c->d_l0c, c->d_l0c_base));
+    HIP_TRY(launch_prepare(c->stream, c->cfg.grid_res, c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l3, c->d_l0c, c->d_l0c_base, c->d_cull));
+    {
+        const float off[8] = {-1e30f, -1e30f, -1e30f, 1e30f, 1e30f, 1e30f, 0.0f, 0.0f};   // nothing is culled
+        HIP_TRY(hipMemcpyAsync(c->d_cull + 8, off, sizeof(off), hipMemcpyHostToDevice, c->stream));
+        float box[8];
+        HIP_TRY(hipMemcpyAsync(box, c->d_cull, sizeof(box), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));   // (source and destination are on this stack frame)
+        c->cull_active = box[6] != 0.0f;
+    }
     if (c->scene.use_physical_sky == 1) {
         SkyPrecompute sp = make_sky(c);
         f3 sd, sc_;
@@ -682,7 +699,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             if (!c->d_prim_cache[which] && dalloc(&c->d_prim_cache[which], c->npix) != hipSuccess) { (void)hipGetLastError(); c->d_prim_cache[which] = nullptr; }
             prim = c->d_prim_cache[which];
         }
-        if (c->pooled) HIP_TRY(launch_render_pool(rs, c->cfg.grid_res, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch : c->d_pool_scratch, c->drain_signal, prim));
+        if (c->pooled) HIP_TRY(launch_render_pool(rs, c->cfg.grid_res, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch : c->d_pool_scratch, c->drain_signal, prim, culling(c)));
         else HIP_TRY(launch_render(rs, c->cfg.grid_res, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g));
         c->drain_signalled = c->pooled && c->drain_signal != nullptr;
         HIP_TRY(hipEventRecord(b, rs));

@@ -35,7 +35,8 @@ namespace vrt {
 
 // grid_res (128 or 256) selects the kernel instantiation everywhere below (GridDim, vrt_types.h)
 hipError_t launch_prepare(hipStream_t st, int grid_res, const int8_t* mat, const uint8_t* rgb, uint32_t* grid, unsigned long long* l0,
-                          unsigned long long* l1, unsigned long long* l2, unsigned long long* l3, unsigned long long* l0c, uint32_t* l0c_base);
+                          unsigned long long* l1, unsigned long long* l2, unsigned long long* l3, unsigned long long* l0c, uint32_t* l0c_base,
+                          float* cull /*[6]: cull_ray()'s box, vrt_trace.h*/);
 hipError_t query_render_residency(int grid_res, bool restir, bool instr, int* blocks_per_cu);
 hipError_t launch_render(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                          const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples);
@@ -46,7 +47,8 @@ size_t pool_scratch_bytes(int grid_res, bool restir, int n_blocks);
 hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                               const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold,
                               uint32_t* drain_signal,   // signal memory (or null): receives launch_seq + 1 when the launch starts to drain
-                              PrimaryRecord* prim_cache);       // per-pixel camera-ray records shared by the fused samples (or null), npix entries
+                              PrimaryRecord* prim_cache,        // per-pixel camera-ray records shared by the fused samples (or null), npix entries
+                              bool cull);                       // the instantiation that tests rays against sc.cull (cull_ray, vrt_trace.h)
 hipError_t launch_mat_derived(hipStream_t st, const float* mats, float* mats_x /*[128][8]*/);  // after every material upload
 // spatial reuse over rows [r0, r1); first a per-pixel prepare pass over all rows the launch holds (fp.row0..fp.row1) into gb.geo / gb.src
 hipError_t launch_gris(hipStream_t st, int grid_res, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1);

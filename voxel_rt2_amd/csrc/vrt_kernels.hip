@@ -70,6 +70,34 @@ __global__ void k_build_coarse(const unsigned long long* __restrict__ fine, unsi
     coarse[b] = w;
 }
 
+// Bounding box of the solid voxels (brick granular) grown by VRT_CULL_MARGIN: what cull_ray() (vrt_trace.h) tests rays against.
+// One block; an empty grid gives lo > hi.
+__global__ void k_cull_box(const unsigned long long* __restrict__ l0, int n0, float* __restrict__ out) {
+    __shared__ int s_lo[3][256], s_hi[3][256];
+    int lo[3] = {1 << 20, 1 << 20, 1 << 20}, hi[3] = {-(1 << 20), -(1 << 20), -(1 << 20)};
+    for (int b = threadIdx.x; b < n0 * n0 * n0; b += blockDim.x) {
+        if (l0[b] == 0ULL) continue;
+        const int c[3] = {b % n0, (b / n0) % n0, b / (n0 * n0)};
+        for (int a = 0; a < 3; a++) { lo[a] = min(lo[a], c[a] * 4); hi[a] = max(hi[a], c[a] * 4 + 4); }
+    }
+    for (int a = 0; a < 3; a++) { s_lo[a][threadIdx.x] = lo[a]; s_hi[a][threadIdx.x] = hi[a]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        int l = 1 << 20, h = -(1 << 20);
+        for (int i = 0; i < 256; i++) { l = min(l, s_lo[threadIdx.x][i]); h = max(h, s_hi[threadIdx.x][i]); }
+        out[threadIdx.x] = (float)l - VRT_CULL_MARGIN;
+        out[3 + threadIdx.x] = (float)h + VRT_CULL_MARGIN;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // is there anything to cull: does the grown box leave part of the grid out
+        const float G = (float)(n0 * 4);
+        bool some = false;
+        for (int a = 0; a < 3; a++) some = some || out[a] > 0.0f || out[3 + a] < G;
+        out[6] = some ? 1.0f : 0.0f;
+        out[7] = 0.0f;
+    }
+}
+
 // The fine level without its empty words (Pyramid::l0c, vrt_types.h).  One block of 512 threads, thread i = l1 brick i:
 // exclusive prefix sum of the popcounts, then each thread copies the words behind its set bits in bit order.
 __global__ void k_build_l0c(const unsigned long long* __restrict__ l0, const unsigned long long* __restrict__ l1,
@@ -104,6 +132,7 @@ template <int G_>
 struct LdsPyramid {  // coarse levels in LDS, fine level through L2
     static constexpr int G = G_;
     static constexpr bool flat_descend = false;  // its kernels walk with few active lanes: descend()'s early outs win
+    static constexpr bool cull = true;
     const unsigned long long* l0;
     const unsigned long long* l1;
     const unsigned long long* l2;
@@ -116,9 +145,12 @@ struct LdsPyramid {  // coarse levels in LDS, fine level through L2
 // The pooled kernel's view.  128^3: each l1 word beside its parent l2 word ({w1, w2}[512], one 16-byte LDS read per
 // cell), and the head of the compacted fine level (Pyramid::l0c) in LDS too -- a sparse scene's fine level is a few
 // hundred words, and the fine word is the load every other DDA step depends on (L2: ~700 cycles, LDS: ~130).
-template <int G_>
+// CULL: rays that cannot hit a voxel are not walked (cull_ray, vrt_trace.h).  A launch over a scene whose solids fill the grid
+// has nothing to cull and runs the instantiation without the test (its registers cost a dense 4K frame 2.5 %).
+template <int G_, bool CULL_>
 struct LdsPyramid2 {
     static constexpr int G = G_;
+    static constexpr bool cull = CULL_;
     static constexpr bool flat_descend = true;   // the pooled kernel walks with nearly full waves
     const unsigned long long* l0;
     const ulonglong2* l12;
@@ -143,9 +175,10 @@ struct LdsPyramid2 {
 // they miss LDS by a factor of 13) through L1 / L2 with the current brick's word cached in registers per ray.  A
 // workgroup is eight waves (one per CU: eight 13.5 KB path pools + 32.5 KB of pyramid + the material table = 148 KB of
 // the CU's 160 KB), so the level is staged once per CU.
-template <>
-struct LdsPyramid2<256> {
+template <bool CULL_>
+struct LdsPyramid2<256, CULL_> {
     static constexpr int G = 256;
+    static constexpr bool cull = CULL_;
     static constexpr bool flat_descend = true;
     const unsigned long long* l0;
     const unsigned long long* l1;   // LDS [4096]
@@ -182,8 +215,10 @@ __global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_re
     __shared__ unsigned long long s_l1[N1];
     __shared__ unsigned long long s_l2[N2];
     __shared__ float s_mats[128 * 14];
+    __shared__ float s_cull[8];
     for (int i = threadIdx.x; i < N1; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
     if (threadIdx.x < N2) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
+    if (threadIdx.x < 8) s_cull[threadIdx.x] = sc.cull[threadIdx.x];
     for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
     if (blockIdx.x == 0 && threadIdx.x < VRT_WORK_HEADS) next_counter[threadIdx.x * VRT_WORK_HEAD_STRIDE] = 0u;  // the next launch's heads (idle during this launch)
     if (blockIdx.x == 0 && threadIdx.x == 0) next_counter[1] = 0u;  // and its "drain announced" word
@@ -193,6 +228,7 @@ __global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_re
     P.w3 = (G == 256) ? sc.pyr.l3[0] : 0ULL;
     SceneData scl = sc;
     scl.mats = s_mats;
+    scl.cull = s_cull;
 
     const int lane = threadIdx.x & 63;
     const int tiles_x = (fp.W + 7) >> 3;
@@ -281,7 +317,7 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-template <int G, bool RESTIR, bool INSTR, bool BLACK_SUN>
+template <int G, bool RESTIR, bool INSTR, bool BLACK_SUN, bool CULL>
 // 208 registers per wave (the attribute counts half of the unified file): two waves per SIMD then leave the 96 that
 // k_temporal runs in beside them (see there).  The allocator would take 238; the cap costs 28 bytes of scratch.
 // The ReSTIR instantiation (no overlapped launches, so nothing runs beside it) takes the two-wave maximum of 256.
@@ -297,10 +333,11 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
     __shared__ unsigned long long s_fine[BIG ? 1 : VRT_POOL_FINE_WORDS];
     __shared__ uint32_t s_fine_base[BIG ? 1 : 512];
     __shared__ float s_mats[128 * 14];
+    __shared__ float s_cull[8];
     __shared__ uint32_t s_pool[WAVES][PF_COUNT * VRT_POOL_SLOTS];
     __shared__ uint32_t s_state[WAVES][VRT_POOL_WORDS * 64];
     __shared__ uint32_t s_list[WAVES][VRT_POOL_SLOTS];
-    LdsPyramid2<G> P;
+    LdsPyramid2<G, CULL> P;
     P.l0 = sc.pyr.l0; P.l2 = s_l2;
     if constexpr (BIG) {
         for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
@@ -322,6 +359,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
         P.l12 = s_l12; P.fine_base = s_fine_base; P.fine = s_fine; P.n_fine = n_fine;
     }
     for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
+    if (threadIdx.x < 8) s_cull[threadIdx.x] = sc.cull[threadIdx.x];
     if (blockIdx.x == 0 && threadIdx.x < VRT_WORK_HEADS) next_counter[threadIdx.x * VRT_WORK_HEAD_STRIDE] = 0u;  // the next launch's heads (idle during this launch)
     if (blockIdx.x == 0 && threadIdx.x == 0) next_counter[1] = 0u;  // and its "drain announced" word
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -332,6 +370,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
     __syncthreads();
     SceneData scl = sc;
     scl.mats = s_mats;
+    scl.cull = s_cull;
     constexpr int COLD = ColdLine<RESTIR>::count;
     uint32_t* const cold_wave = cold + (size_t)(blockIdx.x * WAVES + wave) * VRT_POOL_SLOTS * COLD;
 
@@ -523,7 +562,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
                                 rec.x = r4.x; rec.y = r4.y; rec.z = r4.z; rec.w = r4.w;
                                 known = primary_record_valid(rec, prim_tag);
                             }
-                            state[slot] = (uint32_t)(known ? pool_begin_known<G>(fp, s, u, v, sample, rec) : pool_begin<G>(fp, s, u, v, sample, ts));
+                            state[slot] = (uint32_t)(known ? pool_begin_known<G>(fp, s, u, v, sample, rec) : pool_begin<G, CULL>(fp, scl.cull, s, u, v, sample, ts));
                         }
                     }
                 }
@@ -538,13 +577,13 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
     if (INSTR) flush_stats(ts, sc.counters);
 }
 // (the register attribute takes a literal, hence one kernel per budget around the shared body)
-template <int G, bool INSTR, bool BLACK_SUN>
+template <int G, bool INSTR, bool BLACK_SUN, bool CULL>
 __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(VRT_POOL_HALF_VGPRS))) void k_render_pool(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
-    render_pool_body<G, false, INSTR, BLACK_SUN>(fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, drain_value, prim_cache);
+    render_pool_body<G, false, INSTR, BLACK_SUN, CULL>(fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, drain_value, prim_cache);
 }
-template <int G, bool INSTR>
+template <int G, bool INSTR, bool CULL>
 __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(128))) void k_render_pool_restir(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
-    render_pool_body<G, true, INSTR, false>(fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, drain_value, prim_cache);
+    render_pool_body<G, true, INSTR, false, CULL>(fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, drain_value, prim_cache);
 }
 
 // ---- spatial reuse ---------------------------------------------------------------------------
@@ -564,11 +603,14 @@ __global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES) void k_gris(FrameParams fp
     if (threadIdx.x < N2) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
     for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
     for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) s_mats_x[i] = gb.mats_x[i];
+    __shared__ float s_cull[8];
+    if (threadIdx.x < 8) s_cull[threadIdx.x] = sc.cull[threadIdx.x];
     LdsPyramid<G> P;
     P.l0 = sc.pyr.l0; P.l1 = s_l1; P.l2 = s_l2;
     P.w3 = (G == 256) ? sc.pyr.l3[0] : 0ULL;
     SceneData scl = sc;
     scl.mats = s_mats;
+    scl.cull = s_cull;
     GrisBuffers gbl = gb;
     gbl.mats_x = s_mats_x;
     // 16x16 pixel tile per workgroup = four 8x8 wave tiles.  Workgroups go to the 8 XCDs round robin: XCD k takes the
@@ -665,12 +707,15 @@ __global__ void k_detmath_probe(int op, int n, const float* a, const float* b, f
 #define VRT_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
 hipError_t launch_prepare(hipStream_t st, int G, const int8_t* mat, const uint8_t* rgb, uint32_t* grid, unsigned long long* l0,
-                          unsigned long long* l1, unsigned long long* l2, unsigned long long* l3, unsigned long long* l0c, uint32_t* l0c_base) {
+                          unsigned long long* l1, unsigned long long* l2, unsigned long long* l3, unsigned long long* l0c, uint32_t* l0c_base,
+                          float* cull) {
     const int n = G * G * G, n0 = G / 4, n1 = G / 16, n2 = G / 64;
     if (G == 256) hipLaunchKernelGGL(k_pack_grid<256>, dim3((n + 255) / 256), dim3(256), 0, st, mat, rgb, grid);
     else hipLaunchKernelGGL(k_pack_grid<128>, dim3((n + 255) / 256), dim3(256), 0, st, mat, rgb, grid);
     VRT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_build_l0, dim3((n0 * n0 * n0 + 255) / 256), dim3(256), 0, st, mat, l0, G);
+    VRT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_cull_box, dim3(1), dim3(256), 0, st, (const unsigned long long*)l0, n0, cull);
     VRT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_build_coarse, dim3((n1 * n1 * n1 + 255) / 256), dim3(256), 0, st, (const unsigned long long*)l0, l1, n1);
     VRT_LAUNCH_CHECK();
@@ -715,8 +760,8 @@ hipError_t launch_render(hipStream_t st, int grid_res, bool restir, bool instr, 
 int pool_waves_per_block(int grid_res) { return grid_res == 256 ? PoolGeom<256>::waves : PoolGeom<128>::waves; }
 hipError_t query_render_pool_residency(int grid_res, bool restir, bool instr, int* blocks_per_cu) {
     hipError_t e = hipSuccess;
-    if (restir) VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool_restir<G, A>, 64 * PoolGeom<G>::waves, 0)));
-    else VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool<G, A, B>, 64 * PoolGeom<G>::waves, 0)));
+    if (restir) VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool_restir<G, A, true>, 64 * PoolGeom<G>::waves, 0)));
+    else VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool<G, A, B, true>, 64 * PoolGeom<G>::waves, 0)));
     return e;
 }
 size_t pool_scratch_bytes(int grid_res, bool restir, int n_blocks) {
@@ -724,18 +769,22 @@ size_t pool_scratch_bytes(int grid_res, bool restir, int n_blocks) {
 }
 hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                               const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold,
-                              uint32_t* drain_signal, PrimaryRecord* prim_cache) {
+                              uint32_t* drain_signal, PrimaryRecord* prim_cache, bool cull) {
     unsigned* work_counter = work_counters + (launch_seq & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     unsigned* next_counter = work_counters + ((launch_seq + 2u) & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     dim3 g(n_blocks), b(64 * pool_waves_per_block(grid_res));
     // the signal carries launch_seq + 1 of the latest launch that has begun to drain
     // the black-sun variant (scene.py's default light) compiles the light sample out of the shading stage
     const bool black_sun = !((fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f);
+#define VRT_POOL_ARGS g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u, prim_cache
     if (restir) {  // the reservoir needs the light sample whatever the sun's colour
-        VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_render_pool_restir<G, A>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u, prim_cache)));
+        if (cull) VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_render_pool_restir<G, A, true>), VRT_POOL_ARGS)));
+        else VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_render_pool_restir<G, A, false>), VRT_POOL_ARGS)));
     } else {
-        VRT_BY_GRID(grid_res, VRT_BY_2(instr, black_sun, hipLaunchKernelGGL((k_render_pool<G, A, B>), g, b, 0, st, fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, launch_seq + 1u, prim_cache)));
+        if (cull) VRT_BY_GRID(grid_res, VRT_BY_2(instr, black_sun, hipLaunchKernelGGL((k_render_pool<G, A, B, true>), VRT_POOL_ARGS)));
+        else VRT_BY_GRID(grid_res, VRT_BY_2(instr, black_sun, hipLaunchKernelGGL((k_render_pool<G, A, B, false>), VRT_POOL_ARGS)));
     }
+#undef VRT_POOL_ARGS
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }

@@ -191,12 +191,12 @@ VRT_DEV int slot_state_after_walk(float t, float floor_t) {
 
 // Set up the closest-hit ray of the path in `s` (its pos and dir are stored already): floor distance and the
 // prepared walk.  A ray that misses the grid box has nothing to walk and goes straight to SHADE / ESCAPE.
-template <int G>
-VRT_DEV int pool_launch_ray(const FrameParams& fp, const SlotRef& s, f3 pos, f3 d, TraceStats& ts) {
+template <int G, bool CULL = true>
+VRT_DEV int pool_launch_ray(const FrameParams& fp, const float* cull, const SlotRef& s, f3 pos, f3 d, TraceStats& ts) {
     const float ft = floor_probe(fp, pos, d);
     s.sf(PF_FLOOR_T, ft);
     RayWalk w;
-    const bool alive = walk_prepare<G>(world_to_voxel<G>(pos), d, w);
+    const bool alive = walk_prepare<G, CULL>(world_to_voxel<G>(pos), d, w, cull);
     ts.rays += 1u;
     walk_store(s, w);
     walk_store_constants(s, w);
@@ -240,12 +240,12 @@ VRT_DEV int pool_begin_known(const FrameParams& fp, const SlotRef& s, int u, int
 }
 
 // BEGIN: work item (u, v, sample) -> camera ray pending.
-template <int G>
-VRT_DEV int pool_begin(const FrameParams& fp, const SlotRef& s, int u, int v, int sample, TraceStats& ts) {
+template <int G, bool CULL = true>
+VRT_DEV int pool_begin(const FrameParams& fp, const float* cull, const SlotRef& s, int u, int v, int sample, TraceStats& ts) {
     Path<false> p;
     path_begin(fp, p, u, v, sample);
     path_store_hot(s, p);
-    return pool_launch_ray<G>(fp, s, p.pos, p.d, ts);
+    return pool_launch_ray<G, CULL>(fp, cull, s, p.pos, p.d, ts);
 }
 
 // SHADE (KIND = HIT_SOMETHING) and ESCAPE (KIND = HIT_NOTHING): rebuild the closest hit from the slot, run the
@@ -277,7 +277,7 @@ VRT_DEV int pool_shade(const FrameParams& fp, const SceneData& sc, const PyrT& P
     }
     if (RESTIR || depth == 0) path_store_cold(cold_line, p);
     path_store_hot(s, p);
-    return pool_launch_ray<PyrT::G>(fp, s, p.pos, p.d, ts);
+    return pool_launch_ray<PyrT::G, PyrT::cull>(fp, sc.cull, s, p.pos, p.d, ts);
 }
 
 }  // namespace vrt

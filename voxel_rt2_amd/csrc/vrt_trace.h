@@ -25,6 +25,8 @@ struct SceneData {
     const float* mats;      // [128][14]
     SkyTables sky;
     Counters* counters;     // instrumented build only
+    const float* cull;      // [8] the solid voxels' bounding box grown by VRT_CULL_MARGIN, voxel units: lo xyz, hi xyz (cull_ray);
+                            // [6] != 0: the box leaves part of the grid out, i.e. there are rays to cull (a dense scene: 0)
 };
 
 struct BrickCache { int key; unsigned long long word; };
@@ -149,6 +151,7 @@ template <int G_>
 struct GlobalPyramid {  // all brick levels read from global memory
     static constexpr int G = G_;
     static constexpr bool flat_descend = false;
+    static constexpr bool cull = true;   // rays that cannot hit a voxel are not walked (cull_ray); false compiles the test out
     Pyramid p;
     VRT_DEV unsigned long long load_l0(int i) const { return p.l0[i]; }
     VRT_DEV unsigned long long load_l1(int i) const { return p.l1[i]; }
@@ -165,9 +168,51 @@ struct GlobalPyramid {  // all brick levels read from global memory
 
 struct TraceOut { float dist; int ix, iy, iz; f3 normal; int iters; };
 
+// ---- rays that cannot hit anything -----------------------------------------------------------------------------------
+// The walk's only observable results are "first solid voxel on the ray" or "none" (distance inf: the caller then ignores
+// cell, normal and step count, pathtracer.py:203-205).  A ray that stays clear of every solid voxel is therefore a miss
+// whatever the walk does on the way, and the part of a ray behind its last chance of a hit need not be walked.  `cull` is
+// the bounding box of the solid voxels grown by VRT_CULL_MARGIN on every side (built by prepare, brick granular):
+//   * a ray that misses the grown box misses every voxel -- no walk at all (and none of the nine divisions of its set-up);
+//   * inside the grid the walk may stop where the ray leaves the grown box (G = 128, see below).
+// Why a margin, and why 8: (1) the slab test below is approximate (v_rcp_f32, no correctly rounded division): its error
+// moves the box faces by < 1e-4 voxel; (2) the reference's loop also ends after 512 steps with a FINITE distance -- "a hit
+// on an empty cell" (raytracer.py:103) -- and a culled ray must not be one of those: a point 8 or more
+// voxels from every solid lies in empty cells at LODs 0-3 (an aligned cube of edge <= 8 around it holds no solid), so the
+// unwalked part advances a LOD-3 cell (8 voxels) or more per step: <= 3 * 256 / 8 = 96 steps, and the walked part of a 128
+// grid at most 3 * 128 = 384 cell-boundary crossings: 512 is out of reach.  (At 256 a walked part could in principle
+// use more than 416 steps, so the walk is not cut short there -- only whole rays are culled.)
+// Rays with a zero or non-finite direction component are left to the walk (their slab arithmetic is the reference's NaN
+// business).  Instrumented launches that count the reference's work get a box that holds everything: nothing is culled.
+#ifndef VRT_CULL_MARGIN
+#define VRT_CULL_MARGIN 8.0f
+#endif
+VRT_DEV float fast_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+// false: the ray (origin o, direction d, voxel units) cannot hit a solid voxel.  true: it may; t_exit = where it leaves
+// the grown box (inf when no statement is made).
+VRT_DEV bool cull_ray(const float* cull, f3 o, f3 d, float& t_exit) {
+    t_exit = DM_INF;
+    if (cull[6] == 0.0f) return true;   // the box is the grid (or culling is off): the same for every ray of the launch
+    const f3 ad = abs3(d);
+    if (!(ad.x > 0.0f && ad.y > 0.0f && ad.z > 0.0f && ad.x < DM_INF && ad.y < DM_INF && ad.z < DM_INF)) return true;
+    const f3 inv = mk3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+    const f3 a = (mk3(cull[0], cull[1], cull[2]) - o) * inv, b = (mk3(cull[3], cull[4], cull[5]) - o) * inv;
+    const float tn = dm_max(dm_max(dm_min(a.x, b.x), dm_min(a.y, b.y)), dm_min(a.z, b.z));
+    const float tf = dm_min(dm_min(dm_max(a.x, b.x), dm_max(a.y, b.y)), dm_max(a.z, b.z));
+    if (!(tf >= dm_max(tn, 0.0f))) return false;   // also an empty box (lo > hi: no solids at all) and a NaN
+    t_exit = tf;
+    return true;
+}
+
 // raytracer.py:72-155 with ray_min_t = eps, ray_max_t = inf (the only call site, pathtracer.py:201-202).
 template <class PyrT>
-VRT_DEV void raytrace(const PyrT& P, f3 o, f3 d, TraceOut& r, int& queries) {
+VRT_DEV void raytrace(const PyrT& P, f3 o, f3 d, TraceOut& r, int& queries, const float* cull) {
     float hit_distance = DM_INF;
     int ix = -1, iy = -1, iz = -1;
     f3 hn = mk3(0.0f);
@@ -175,6 +220,13 @@ VRT_DEV void raytrace(const PyrT& P, f3 o, f3 d, TraceOut& r, int& queries) {
     queries = 0;
     constexpr int G = PyrT::G;
     const float res = (float)G;
+    float t_exit = DM_INF;
+    if constexpr (PyrT::cull) {
+        if (!cull_ray(cull, o, d, t_exit)) {  // clear of every solid voxel: a miss
+            r.dist = DM_INF; r.ix = -1; r.iy = -1; r.iz = -1; r.normal = hn; r.iters = 0;
+            return;
+        }
+    }
 
     // math_utils.py:103-123 against the box [0,G]^3
     float near_t = -DM_INF, far_t = DM_INF;
@@ -195,7 +247,8 @@ VRT_DEV void raytrace(const PyrT& P, f3 o, f3 d, TraceOut& r, int& queries) {
         const f3 inv_dir = mk3(1.0f / dm_abs(d.x), 1.0f / dm_abs(d.y), 1.0f / dm_abs(d.z));
         const f3 sd = mk3(sgn(d.x), sgn(d.y), sgn(d.z));
         int lod = 0;
-        const float far = dm_min(DM_INF, far_t) - VRT_EPS;
+        float far = dm_min(DM_INF, far_t) - VRT_EPS;
+        if (G == 128) far = dm_min(far, t_exit);   // behind the grown box nothing can be hit (cull_ray)
 
         f3 id = abs3(p0 - res * 0.5f);
         float md = dm_max(dm_max(id.x, id.y), id.z);
@@ -256,14 +309,16 @@ struct RayWalk {
 };
 
 // raytracer.py:81-101: clip against the grid box, first cell, entry-face normal.  False = the box is missed.
-template <int G>
-VRT_DEV bool walk_prepare(f3 o, f3 d, RayWalk& w) {
+template <int G, bool CULL = true>
+VRT_DEV bool walk_prepare(f3 o, f3 d, RayWalk& w, const float* cull) {
     w.o = o; w.d = d;
     w.sd = mk3(sgn(d.x), sgn(d.y), sgn(d.z));
     w.t = DM_INF; w.far = 0.0f;
     w.ix = -1; w.iy = -1; w.iz = -1; w.lod = 0; w.iters = 0;
     w.hn = mk3(0.0f);
     w.inv_dir = mk3(0.0f);
+    float t_exit = DM_INF;
+    if constexpr (CULL) { if (!cull_ray(cull, o, d, t_exit)) return false; }   // clear of every solid voxel: nothing to walk, the ray is a miss
     const float res = (float)G;
     float near_t = -DM_INF, far_t = DM_INF;
 #define VRT_SLAB(oc, dc)                                                     \
@@ -281,6 +336,7 @@ VRT_DEV bool walk_prepare(f3 o, f3 d, RayWalk& w) {
     w.ix = (int)c.x; w.iy = (int)c.y; w.iz = (int)c.z;
     w.inv_dir = mk3(1.0f / dm_abs(d.x), 1.0f / dm_abs(d.y), 1.0f / dm_abs(d.z));
     w.far = dm_min(DM_INF, far_t) - VRT_EPS;
+    if (G == 128) w.far = dm_min(w.far, t_exit);
     const f3 id = abs3(p0 - res * 0.5f);
     const float md = dm_max(dm_max(id.x, id.y), id.z);
     w.hn = mk3(md == id.x ? 1.0f : 0.0f, md == id.y ? 1.0f : 0.0f, md == id.z ? 1.0f : 0.0f);
@@ -409,7 +465,7 @@ VRT_DEV void next_hit(const FrameParams& fp, const SceneData& sc, const PyrT& P,
     const f3 eye = world_to_voxel<PyrT::G>(pos);
     TraceOut tr;
     int nq;
-    raytrace(P, eye, d, tr, nq);
+    raytrace(P, eye, d, tr, nq, sc.cull);
     ts.rays += 1u; ts.iters += (unsigned)tr.iters; ts.queries += (unsigned)nq;
     VRT_REGION(SHADOW ? 3 : 9);  // ray set-up + result (one entry per ray)
     hit_voxel<SHADOW, PyrT::G>(fp, sc, eye, d, tr, h, ts);
