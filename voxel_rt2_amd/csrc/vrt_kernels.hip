@@ -438,7 +438,10 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
 
         if (stage == SLOT_RAY) {
             VRT_REGION(14);
-            const int park = (n >= 64) ? VRT_POOL_PARK : 0;  // suspending only pays when other stages then have work
+#ifndef VRT_POOL_PARK_MIN
+#define VRT_POOL_PARK_MIN 64
+#endif
+            const int park = (n >= VRT_POOL_PARK_MIN) ? VRT_POOL_PARK : 0;  // suspending only pays when other stages then have work
             int head = 0;
             bool active = false, ended = false;
             RayWalk w;
