@@ -412,12 +412,6 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         gb.res_out[idx] = gb.res_in[idx];
         return;
     }
-    int cmat_id;
-    const Material cmat = material_from_bits(sc.mats, cg.mat, cmat_id);
-    Surf cds;  // the centre pixel's shading frame (pathtracer.py:731-732 with dst = centre)
-    surf_set(cds, cmat, load_mat_derived(gb.mats_x, cmat_id), cn1, cg.v, cross3(cn1, cg.ty), cg.ty);
-    const SurfShared cdsc = surf_shared(cds, true, true, true);   // destination of every neighbour's sample, whatever its lobe
-    const int cl = center.z.lobes % 10;                           // the lobe the centre's sample leaves every neighbour's vertex by
     int valid = 0;
     float canonical_mis = 1.0f;
     f3 chosen_d = mk3(0.0f), chosen_s = mk3(0.0f);
@@ -462,6 +456,16 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         cw /= c_p_hat * nb_M + lum(center.z.F) * center.M / (float)max_taps;
         canonical_mis += 1.0f - cw;
     }
+    // Register budget (the kernel is held to 256 and waits on spill reloads): the first tap loop carries the centre's sample,
+    // the second the centre's shading point and the output reservoir -- neither needs the other's, so the shading point is
+    // built only now and the centre's sample is read again after the second loop instead of being kept across it.
+    const float center_M = center.M;
+    int cmat_id;
+    const Material cmat = material_from_bits(sc.mats, cg.mat, cmat_id);
+    Surf cds;  // the centre pixel's shading frame (pathtracer.py:731-732 with dst = centre)
+    surf_set(cds, cmat, load_mat_derived(gb.mats_x, cmat_id), cn1, cg.v, cross3(cn1, cg.ty), cg.ty);
+    SurfShared cdsc;   // destination of every neighbour's sample, whatever its lobe: from the prepare pass (= surf_shared(cds, 1, 1, 1))
+    cdsc.lambert = cg.lambert; cdsc.sheen_col = cg.sheen_col; cdsc.spec_col = cg.spec_col; cdsc.fv = cg.fv; cdsc.g_v = cg.g_v; cdsc.gc_v = cg.gc_v;
     for (unsigned m = accepted; m != 0u; m &= m - 1u) {
         const int i = __builtin_ctz(m);
         const int packed = taps.off[i * taps.off_stride];
@@ -477,7 +481,7 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         float p_hat = lum(sd + ss);
         float p_hat_n = p_hat / jac;
         float nw = p_hat_n * nb.M;
-        nw /= p_hat_n * nb.M + p_hat * center.M / (float)max_taps;
+        nw /= p_hat_n * nb.M + p_hat * center_M / (float)max_taps;
         if (dm_isinf(nw) || dm_isnan(nw)) nw = 0.0f;
 
         nb.z.F = sd + ss;
@@ -485,6 +489,10 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         valid += 1;
     }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+    __asm__ volatile("" ::: "memory");   // (so that the values below are loaded here, not carried in registers through the loop above)
+#endif
+    gris_load_src(center, center_rc_ty, center_sky_t, center_pre, gb.src[idx]);
     // visibility of the chosen sample's reconnection (:959-967)
     bool force_canonical = false;
     const bool out_escape = near_zero3(outr.z.rc_normal);
