@@ -98,3 +98,28 @@ def test_config5_full_size_shard_matches_oracle():
     assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
     assert np.array_equal(frames[0][rows[0]:rows[1]].view(np.uint32), shard.view(np.uint32))
     assert np.isfinite(frames[0]).all() and frames[0].mean() > 0.01
+
+
+@pytest.mark.parametrize("grid", [128, 256])
+@pytest.mark.parametrize("fill", ["empty", "full", "one_voxel"])
+def test_degenerate_grids(render_schedule, grid, fill):
+    """No solid voxel at all (the culling box is empty: every ray is a miss without a walk), every voxel solid (nothing to cull,
+    every ray stops in its first cell), a single voxel in a corner (a tiny box far from the camera axis) -- each over a lit floor,
+    at both grid sizes, against the oracle."""
+    mat, rgb = scenes.empty(grid)
+    if fill == "full":
+        mat[...] = 1
+        rgb[...] = (180, 140, 90)
+    elif fill == "one_voxel":
+        mat[grid - 1, grid // 2, 0] = 11
+        rgb[grid - 1, grid // 2, 0] = (255, 64, 32)
+    params = dict(exposure=1.0, voxel_edges=0.06, floor_height=-0.3, floor_color=(0.7, 0.6, 0.5), floor_material=1,
+                  background_color=(0.2, 0.3, 0.5), light_direction=(0.3, 1.0, 0.2), light_cone=0.1, light_color=(1.0, 0.9, 0.8),
+                  use_physical_sky=0, use_clouds=0)
+    cfg = host.make_config(136, 84, voxel_edges=0.06, exposure=1.0, max_depth=5, seed=17, grid_res=grid)
+    g, o = NativeSession(_lib.load(), "vrt_", cfg), orc.Oracle(cfg)
+    for s in (g, o):
+        orc.setup(s, mat, rgb, params)
+        s.accumulate(3)
+    assert_same(g, o)
+    assert np.isfinite(g.fetch_hdr()).all() and g.fetch_hdr().mean() > 0.01
