@@ -144,3 +144,30 @@ def test_spatial_reuse_bsdf_path_equals_render_bsdf_path():
     lib.emu_bsdf_selftest.argtypes = [C.c_int, C.c_uint32]
     lib.emu_bsdf_selftest.restype = C.c_int
     assert lib.emu_bsdf_selftest(20000, 11) == 0
+
+
+@pytest.mark.parametrize("fill", ["empty", "full", "one_voxel", "far_corner_blocks"])
+def test_degenerate_grids(fill):
+    """The culling box at its extremes: no solid voxel (an empty box: every ray a miss), all solid (the box is the grid),
+    a single voxel / two small blocks in opposite corners (a box that is mostly air) -- over a lit floor."""
+    mat, rgb = scenes.empty()
+    if fill == "full":
+        mat[...] = 1
+        rgb[...] = (180, 140, 90)
+    elif fill == "one_voxel":
+        mat[127, 64, 0] = 11
+        rgb[127, 64, 0] = (255, 64, 32)
+    elif fill == "far_corner_blocks":
+        mat[2:9, 60:70, 3:8] = 21
+        rgb[2:9, 60:70, 3:8] = (40, 200, 90)
+        mat[118:126, 66:72, 119:127] = 1
+        rgb[118:126, 66:72, 119:127] = (220, 210, 60)
+    params = dict(exposure=1.0, voxel_edges=0.06, floor_height=-0.3, floor_color=(0.7, 0.6, 0.5), floor_material=1,
+                  background_color=(0.2, 0.3, 0.5), light_direction=(0.3, 1.0, 0.2), light_cone=0.1, light_color=(1.0, 0.9, 0.8),
+                  use_physical_sky=0, use_clouds=0)
+    cfg = host.make_config(88, 56, voxel_edges=0.06, exposure=1.0, max_depth=5, seed=17)
+    o, e = orc.Oracle(cfg, threads=4), emu.Emulated(cfg)
+    for s in (o, e):
+        orc.setup(s, mat, rgb, params)
+        s.accumulate(2)
+    assert_same(o, e)
