@@ -36,4 +36,8 @@ for scene in sys.argv[1:] or ["s1", "sunlit", "dense"]:
         tot = sum(cyc.values())
         print("  pool wave-cycles by stage: " + "  ".join(f"{nm} {100 * cyc[k] / tot:.1f}%" for k, nm in
               ((0, "BEGIN"), (1, "WALK"), (2, "SHADE"), (3, "ESCAPE"), (5, "census"), (4, "start/exit"))))
+    sub = [int(out[52 + k]) for k in range(4)]
+    if sum(sub) and sum(cyc.values()):
+        print("  BEGIN, of all pool wave-cycles: " + "  ".join(f"{nm} {100 * sub[k] / tot:.1f}%" for k, nm in
+              enumerate(("work reservation (atomic round trip)", "record read + check", "set-up from a record", "set-up with a ray"))))
     s.close()

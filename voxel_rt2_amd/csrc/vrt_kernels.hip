@@ -395,6 +395,10 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
     // summed in registers and flushed once at the end: an atomic per stage switch from 2048 waves saturates the
     // words it lands on and slows every other memory operation (it made the first version of this clock useless)
     unsigned long long t_stage[6] = {0ULL, 0ULL, 0ULL, 0ULL, 0ULL, 0ULL};
+    unsigned long long t_sub[4] = {0ULL, 0ULL, 0ULL, 0ULL};   // BEGIN: reservation, record read, set-up from a record, set-up with a ray
+#define VRT_SUB_CLOCK(q) do { __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_readcyclecounter(); t_sub[q] += t_ - t_sub_prev; t_sub_prev = t_; } while (0)
+#define VRT_SUB_START() do { __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); t_sub_prev = __builtin_readcyclecounter(); } while (0)
+    unsigned long long t_sub_prev = 0ULL;
 #define VRT_POOL_CLOCK(next_stage)                                                                              \
     do {                                                                                                        \
         const unsigned long long t_now = __builtin_readcyclecounter();                                          \
@@ -403,6 +407,8 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
     } while (0)
 #else
 #define VRT_POOL_CLOCK(next_stage) ((void)0)
+#define VRT_SUB_CLOCK(q) ((void)0)
+#define VRT_SUB_START() ((void)0)
 #endif
     for (;;) {
         wave_lds_sync();
@@ -463,12 +469,8 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
                     state[slot] = (uint32_t)slot_state_after_walk<G>(w.t, s.f(PF_FLOOR_T));
                     if (prim_cache) {  // the camera ray of a pixel's sample 0: leave its record for the other samples
                         const uint32_t ids = s.u(PF_IDS);
-                        if ((ids >> 24) == 0u) {  // depth 0, sample 0
-                            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                            const PrimaryRecord r = primary_record(s, prim_tag);
-                            const u32x4 r4 = {r.x, r.y, r.z, r.w};  // one 16-byte store; the check word tells a reader whether it saw all of it
-                            *(u32x4*)&prim_cache[((int)((ids >> 12) & 0xfffu) - fp.row0) * fp.W + (int)(ids & 0xfffu)] = r4;
-                        }
+                        if ((ids >> 24) == 0u)  // depth 0, sample 0 (the check word tells a reader whether it saw all of the record)
+                            primary_record_store(&prim_cache[((int)((ids >> 12) & 0xfffu) - fp.row0) * fp.W + (int)(ids & 0xfffu)], primary_record(s, prim_tag));
                     }
                     ts.iters += (unsigned)(w.iters - iters0);
                     ended = false;
@@ -511,6 +513,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
             unsigned base = 0u, limit = 0u;  // items [base, limit) go to lanes 0.. of this BEGIN
             unsigned range0 = 0u, per_sample = 1u;  // first item of the range they belong to, items per sample in it
             if (stage == SLOT_EMPTY) {
+                VRT_SUB_START();
                 // pull from the current head; a used-up range sends the wave on to the next head (and this BEGIN
                 // hands out nothing: the census runs again)
                 unsigned got = 0u;
@@ -533,22 +536,27 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
                     }
                 }
                 if (base > limit) base = limit;
+                VRT_SUB_CLOCK(0);
             }
             if (lane < take) {
-                const int slot = (int)list[lane];
                 SlotRef s;
-                s.base = pool + slot; s.stride = VRT_POOL_SLOTS;
-                uint32_t* const cold_line = cold_wave + slot * COLD;
+                s.stride = VRT_POOL_SLOTS;
                 if (stage == SLOT_SHADE) {
                     VRT_REGION(11);
-                    state[slot] = (uint32_t)pool_shade<HIT_SOMETHING, BLACK_SUN, RESTIR>(fp, scl, P, out, s, cold_line, ts);
+                    const int slot = (int)list[lane];
+                    s.base = pool + slot;
+                    state[slot] = (uint32_t)pool_shade<HIT_SOMETHING, BLACK_SUN, RESTIR>(fp, scl, P, out, s, cold_wave + slot * COLD, ts);
                 } else if (stage == SLOT_ESCAPE) {
                     VRT_REGION(12);
-                    state[slot] = (uint32_t)pool_shade<HIT_NOTHING, false, RESTIR>(fp, scl, P, out, s, cold_line, ts);
+                    const int slot = (int)list[lane];
+                    s.base = pool + slot;
+                    state[slot] = (uint32_t)pool_shade<HIT_NOTHING, false, RESTIR>(fp, scl, P, out, s, cold_wave + slot * COLD, ts);
                 } else {
                     VRT_REGION(13);
                     const unsigned my = base + (unsigned)lane;
                     if (my < limit) {
+                        const int slot = (int)list[lane];
+                        s.base = pool + slot;
                         const unsigned j = my - range0;  // sample-major inside the range (n_samples <= 4)
                         const int sample = (int)(j >= per_sample) + (int)(j >= 2u * per_sample) + (int)(j >= 3u * per_sample);
                         const unsigned rem = j - (unsigned)sample * per_sample;
@@ -558,14 +566,22 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
                         if (u < fp.W && v < fp.row1 && !outside_render_area(fp, (float)u, (float)v)) {
                             bool known = false;
                             PrimaryRecord rec;
-                            rec.x = rec.y = rec.z = rec.w = 0u;
+                            rec.x = rec.y = rec.z = rec.dx = rec.dy = rec.dz = rec.ft = rec.w = 0u;
                             if (prim_cache && sample > 0) {
-                                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                                const u32x4 r4 = __builtin_nontemporal_load((const u32x4*)&prim_cache[(v - fp.row0) * fp.W + u]);  // one 16-byte load past L1: another CU wrote it
-                                rec.x = r4.x; rec.y = r4.y; rec.z = r4.z; rec.w = r4.w;
+                                rec = primary_record_load(&prim_cache[(v - fp.row0) * fp.W + u]);
                                 known = primary_record_valid(rec, prim_tag);
                             }
-                            state[slot] = (uint32_t)(known ? pool_begin_known<G>(fp, s, u, v, sample, rec) : pool_begin<G, CULL>(fp, scl.cull, s, u, v, sample, ts));
+                            VRT_SUB_CLOCK(1);
+                            int st;
+                            if (known) st = pool_begin_known<G>(fp, s, u, v, sample, rec);
+                            else {
+                                st = pool_begin<G, CULL>(fp, scl.cull, s, u, v, sample, ts);
+                                // a camera ray with nothing to walk (it misses the grid or every solid voxel) is finished here: its
+                                // record is left here too
+                                if (prim_cache && sample == 0 && st != SLOT_RAY) primary_record_store(&prim_cache[(v - fp.row0) * fp.W + u], primary_record(s, prim_tag));
+                            }
+                            state[slot] = (uint32_t)st;
+                            VRT_SUB_CLOCK(sample > 0 ? 2 : 3);
                         }
                     }
                 }
@@ -576,6 +592,8 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
 #if defined(VRT_DIAG_REGIONS)
     if (lane == 0)
         for (int q = 0; q < 6; q++) atomicAdd(&g_vrt_region[2 * (20 + q)], t_stage[q]);
+    if (lane == 0)
+        for (int q = 0; q < 4; q++) atomicAdd(&g_vrt_region[52 + q], t_sub[q]);
 #endif
     if (INSTR) flush_stats(ts, sc.counters);
 }

@@ -142,18 +142,23 @@ struct Path {
     typename std::conditional<RESTIR, PathRestir, NoRestir>::type rs;
 };
 
+// get_cast_dir (pathtracer.py:293-309): the camera ray through pixel (u, v).  The same for every sample of a frame (the
+// jitter is drawn once per frame, :264-265).
+VRT_DEV f3 camera_ray_dir(const FrameParams& fp, int u, int v) {
+    f2 tc = pixel_texcoord(fp, (float)u, (float)v);
+    if (fp.camera_is_moving == 0) { tc.x = tc.x + fp.taa_jitter.x * 0.5f; tc.y = tc.y + fp.taa_jitter.y * 0.5f; }
+    const f3 dv = norm3(screen_to_view(tc, 1.0f, fp.proj_inv));
+    return xform(fp.view_inv, dv, 0.0f);
+}
 // generate_new_sample + get_cast_dir (pathtracer.py:293-347)
 template <bool RESTIR>
-VRT_DEV void path_begin(const FrameParams& fp, Path<RESTIR>& p, int u, int v, int sample) {
+VRT_DEV void path_begin_along(const FrameParams& fp, Path<RESTIR>& p, int u, int v, int sample, f3 d) {  // d = camera_ray_dir(fp, u, v)
     p.pix_u = u;
     p.pix_v = v;
     p.sample = sample;
     p.primary_pos = mk3(0.0f);
     p.rng = dm_rng_init(fp.seed, fp.frame + (uint32_t)sample, (uint32_t)(v * fp.W + u), 0u);
-    f2 tc = pixel_texcoord(fp, (float)u, (float)v);
-    if (fp.camera_is_moving == 0) { tc.x = tc.x + fp.taa_jitter.x * 0.5f; tc.y = tc.y + fp.taa_jitter.y * 0.5f; }
-    f3 dv = norm3(screen_to_view(tc, 1.0f, fp.proj_inv));
-    p.d = xform(fp.view_inv, dv, 0.0f);
+    p.d = d;
     p.pos = fp.camera_pos;
     p.thr = mk3(1.0f);
     p.contrib = mk3(0.0f);
@@ -177,6 +182,8 @@ VRT_DEV void path_begin(const FrameParams& fp, Path<RESTIR>& p, int u, int v, in
         p.rs.rc_lobe = 0;
     }
 }
+template <bool RESTIR>
+VRT_DEV void path_begin(const FrameParams& fp, Path<RESTIR>& p, int u, int v, int sample) { path_begin_along(fp, p, u, v, sample, camera_ray_dir(fp, u, v)); }
 
 // What the caller already knows about the hit handed to path_shade(): lets a stage that only ever sees one kind
 // (vrt_pool.h) drop the other kind's code.

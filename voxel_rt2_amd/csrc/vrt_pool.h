@@ -214,29 +214,50 @@ VRT_DEV int pool_launch_ray(const FrameParams& fp, const float* cull, const Slot
 // only if that word matches the payload it read and the launch it runs in.  A stale record (other launch), a missing one
 // and a torn one -- words of two different stores -- all fail the check (a tear passes with probability 2^-32) and the
 // ray is walked.  The record is still written and read with one 16-byte instruction each (observed untorn on gfx950).
-struct alignas(16) PrimaryRecord { uint32_t x, y, z, w; };  // PF_T, PF_CELL_XY, PF_CELL_Z, check word
-VRT_DEV uint32_t primary_check(uint32_t x, uint32_t y, uint32_t z, uint32_t tag) {
-    uint32_t h = x * 0x9E3779B1u;
-    h = (h ^ (h >> 15)) + y * 0x85EBCA77u;
-    h = (h ^ (h >> 13)) + z * 0xC2B2AE3Du;
-    h ^= h >> 16;
+// The record also carries what every sample of the pixel would work out again before it could use the hit: the ray's
+// direction (camera_ray_dir: a matrix, a perspective divide and a normalisation -- 15 correctly rounded divisions and a
+// square root) and its floor distance (floor_probe), as the bits sample 0 computed.  Two 16-byte halves; the check word
+// covers all seven payload words, so halves of two different stores fail it like any other tear.
+struct alignas(16) PrimaryRecord { uint32_t x, y, z, dx, dy, dz, ft, w; };  // PF_T, PF_CELL_XY, PF_CELL_Z, PF_DIR[3], PF_FLOOR_T, check word
+VRT_DEV uint32_t primary_check(const PrimaryRecord& r, uint32_t tag) {
+    uint32_t h = r.x * 0x9E3779B1u;
+    h = (h ^ (h >> 15)) + r.y * 0x85EBCA77u;
+    h = (h ^ (h >> 13)) + r.z * 0xC2B2AE3Du;
+    h = (h ^ (h >> 16)) + r.dx * 0x27D4EB2Fu;
+    h = (h ^ (h >> 15)) + r.dy * 0x165667B1u;
+    h = (h ^ (h >> 13)) + r.dz * 0x9E3779B1u;
+    h = (h ^ (h >> 16)) + r.ft * 0x85EBCA77u;
+    h ^= h >> 15;
     return h ^ tag;
 }
+// the record of the camera ray whose walk (or set-up, when there was nothing to walk) has just been stored in `s`
 VRT_DEV PrimaryRecord primary_record(const SlotRef& s, uint32_t tag) {
     PrimaryRecord r;
-    r.x = s.u(PF_T); r.y = s.u(PF_CELL_XY); r.z = s.u(PF_CELL_Z); r.w = primary_check(r.x, r.y, r.z, tag);
+    r.x = s.u(PF_T); r.y = s.u(PF_CELL_XY); r.z = s.u(PF_CELL_Z);
+    r.dx = s.u(PF_DIR); r.dy = s.u(PF_DIR + 1); r.dz = s.u(PF_DIR + 2); r.ft = s.u(PF_FLOOR_T);
+    r.w = primary_check(r, tag);
     return r;
 }
-VRT_DEV bool primary_record_valid(const PrimaryRecord& r, uint32_t tag) { return r.w == primary_check(r.x, r.y, r.z, tag); }
+VRT_DEV bool primary_record_valid(const PrimaryRecord& r, uint32_t tag) { return r.w == primary_check(r, tag); }
+typedef unsigned int vrt_u32x4 __attribute__((ext_vector_type(4)));
+VRT_DEV void primary_record_store(PrimaryRecord* at, const PrimaryRecord& r) {  // two 16-byte stores
+    const vrt_u32x4 a = {r.x, r.y, r.z, r.dx}, b = {r.dy, r.dz, r.ft, r.w};
+    ((vrt_u32x4*)at)[0] = a; ((vrt_u32x4*)at)[1] = b;
+}
+VRT_DEV PrimaryRecord primary_record_load(const PrimaryRecord* at) {  // two 16-byte loads past L1: another CU wrote it
+    const vrt_u32x4 a = __builtin_nontemporal_load((const vrt_u32x4*)at), b = __builtin_nontemporal_load((const vrt_u32x4*)at + 1);
+    PrimaryRecord r;
+    r.x = a.x; r.y = a.y; r.z = a.z; r.dx = a.w; r.dy = b.x; r.dz = b.y; r.ft = b.z; r.w = b.w;
+    return r;
+}
 template <int G>
-VRT_DEV int pool_begin_known(const FrameParams& fp, const SlotRef& s, int u, int v, int sample, PrimaryRecord rec) {
+VRT_DEV int pool_begin_known(const FrameParams& fp, const SlotRef& s, int u, int v, int sample, const PrimaryRecord& rec) {
     Path<false> p;
-    path_begin(fp, p, u, v, sample);
+    path_begin_along(fp, p, u, v, sample, mk3(dm_u2f(rec.dx), dm_u2f(rec.dy), dm_u2f(rec.dz)));
     path_store_hot(s, p);
-    const float ft = floor_probe(fp, p.pos, p.d);
-    s.sf(PF_FLOOR_T, ft);
+    s.su(PF_FLOOR_T, rec.ft);
     s.su(PF_T, rec.x); s.su(PF_CELL_XY, rec.y); s.su(PF_CELL_Z, rec.z); s.su(PF_ITERS, 0u);
-    return slot_state_after_walk<G>(dm_u2f(rec.x), ft);
+    return slot_state_after_walk<G>(dm_u2f(rec.x), dm_u2f(rec.ft));
 }
 
 // BEGIN: work item (u, v, sample) -> camera ray pending.
