@@ -360,8 +360,9 @@ def test_fused_samples_equal_separate_launches(monkeypatch):
 
 
 def test_overlapped_launches_match_oracle(monkeypatch):
-    """Fused launches of the pooled kernel overlap (three copies of the planes / g-buffer rotating over two render
-    streams).  Seven calls go round every copy more than twice; a moving-camera pass in between
+    """Fused launches of the pooled kernel overlap (five copies of the planes / g-buffer rotating over four render
+    streams for a frame this size; tests/test_gpu_pipeline.py runs both depths over more launches).
+    Seven calls go round every copy; a moving-camera pass in between
     forces the fall back to the single copy (and the copy-back of what stale readers expect there).  Every buffer
     must equal the oracle's after every phase, and the run with VRT_OVERLAP=0."""
     mat, rgb, params = scenes.scene_sunlit(0)

@@ -75,6 +75,28 @@ def test_host_release_of_the_gate_changes_nothing(reference_frame, monkeypatch):
     assert np.array_equal(hdr.view(np.uint32), reference_frame.view(np.uint32))
 
 
+def test_pipeline_depths_over_many_launches(monkeypatch):
+    """Both depths of the launch pipeline -- two launches of every workgroup slot in flight, and four launches of half the
+    slots each (the default for frames up to 1080p) -- over enough launches that every rotating resource comes round more
+    than once: 5 copies of the sample planes, 6 of the g-buffer normal / depth, 16 sets of work heads."""
+    calls = (4, 4, 3, 4, 2) * 4 + (4,) * 3
+    monkeypatch.setenv("VRT_OVERLAP", "0")
+    ref, st = render(calls)
+    assert st["pipeline_flags"] & 1 == 0
+    monkeypatch.delenv("VRT_OVERLAP")
+    for streams, div in (("4", "2"), ("2", "1"), ("4", "3")):
+        monkeypatch.setenv("VRT_STREAMS", streams)
+        monkeypatch.setenv("VRT_GRID_DIV", div)
+        hdr, st = render(calls)
+        assert st["pipeline_flags"] & 1 == 1
+        assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32)), (streams, div)
+    monkeypatch.delenv("VRT_STREAMS")
+    monkeypatch.delenv("VRT_GRID_DIV")
+    monkeypatch.setenv("VRT_DEEP_ITEMS", "0")   # the policy's other side: this frame is "large"
+    hdr, _ = render(calls)
+    assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32))
+
+
 def test_reserved_workgroup_slots_change_nothing(reference_frame):
     hdr, _ = render(reserve=8)
     assert np.array_equal(hdr.view(np.uint32), reference_frame.view(np.uint32))

@@ -17,6 +17,11 @@
 #include "vrt_kernels.h"
 
 #define VRT_MAX_FUSED 4   // samples of one vrt_accumulate(n) call rendered by a single launch
+#define VRT_MAX_STREAMS 4 // render launches in flight at most (a stream, a pool scratch and a camera-ray table each): 2 or 4 are used
+#define VRT_MAX_SETS 5    // copies of what a render launch writes (set 0 = the canonical buffers): streams + 1 are used
+#define VRT_GB_ROT (VRT_MAX_SETS + 1)   // rotating g-buffer normal / depth copies: copy j is read by temporal passes j and j + 1, and the
+                                       // launch that writes it again only waits for the pass VRT_MAX_SETS launches back
+#define VRT_WORK_SETS 16  // rotating sets of work heads (vrt_kernels.hip: a launch zeroes the set eight launches ahead)
 
 using namespace vrt;
 
@@ -45,7 +50,7 @@ struct vrt_ctx {
     int reserved_cus = 0;             // CUs' worth of workgroup slots the persistent render grid leaves free (vrt_reserve_cus)
     bool pooled = false;              // render through k_render_pool (vrt_pool.h) instead of k_render
     uint32_t* d_pool_scratch = nullptr;
-    PrimaryRecord* d_prim_cache[2] = {nullptr, nullptr};  // camera-ray records of fused launches (one table per render stream)
+    PrimaryRecord* d_prim_cache[VRT_MAX_STREAMS] = {};  // camera-ray records of fused launches (one table per render stream)
     // rows
     int own0 = 0, own1 = 0;   // rows this context produces
     int buf0 = 0, buf1 = 0;   // rows held in the buffers (own + halo)
@@ -72,8 +77,8 @@ struct vrt_ctx {
     f3* d_multi_d = nullptr;        // diffuse colour planes of the samples fused into one launch (allocated on first use)
     f3* d_spec_planes = nullptr;    // VRT_MAX_FUSED specular planes; d_color_s = the last one
     float* d_refl_planes = nullptr; // likewise for the raw reflection depth; d_gb_refl = the last one
-    uint32_t* d_gb_normal[4] = {nullptr, nullptr, nullptr, nullptr};  // rotating: [cur] is written by the next launch, [prev_gb] by the last
-    float* d_gb_depth[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t* d_gb_normal[VRT_GB_ROT] = {};  // rotating: [cur] is written by the next launch, [prev_gb] by the last
+    float* d_gb_depth[VRT_GB_ROT] = {};
     uint32_t* d_gb_mat = nullptr;
     float *d_gb_refl = nullptr, *d_gb_refl_f = nullptr;
     f4 *d_hist_d[2] = {nullptr, nullptr}, *d_hist_s[2] = {nullptr, nullptr};
@@ -83,13 +88,15 @@ struct vrt_ctx {
     GrisSrc* d_gris_src = nullptr;
     float* d_mats_x = nullptr;       // [128][8] mat_derive() of every material row
     int cur = 0;      // g-buffer rotation: render writes [cur], temporal reads [prev_gb] as "prev"
-    int prev_gb = 3;  // the copy the most recent launch wrote
+    int prev_gb = VRT_GB_ROT - 1;  // the copy the most recent launch wrote
     // Overlapped launches (vrt_accumulate): VRT_SETS copies (set 0 = the canonical buffers, alt_*[s - 1] the others) of
     // everything a render launch writes and its temporal pass reads, two render streams and the events that order
     // them, so that launch k+1 starts while launch k drains and temporal pass k runs beside launch k+1.
-    f3* alt_multi_d[2] = {nullptr, nullptr}; f3* alt_spec_planes[2] = {nullptr, nullptr}; float* alt_refl_planes[2] = {nullptr, nullptr};
-    f3* alt_gb_pos[2] = {nullptr, nullptr}; uint32_t* alt_gb_mat[2] = {nullptr, nullptr};
-    uint32_t* alt_pool_scratch = nullptr;  // the second render stream's scratch
+    f3* alt_multi_d[VRT_MAX_SETS - 1] = {}; f3* alt_spec_planes[VRT_MAX_SETS - 1] = {}; float* alt_refl_planes[VRT_MAX_SETS - 1] = {};
+    f3* alt_gb_pos[VRT_MAX_SETS - 1] = {}; uint32_t* alt_gb_mat[VRT_MAX_SETS - 1] = {};
+    uint32_t* alt_pool_scratch[VRT_MAX_STREAMS - 1] = {};  // the other render streams' scratch
+    int n_streams = 2;   // depth of the launch pipeline (ensure_overlap): 2, or 4 with launches of half the workgroups each
+    int grid_div = 1;    // an overlapped launch takes render_blocks / grid_div workgroups
     // A render launch queued behind another on the other render stream would be dispatched at once and sit in the
     // queue until workgroups retire -- which the profiler and the events count as its run time.  Instead the kernel
     // raises this word (HSA signal memory, host visible) to launch_seq + 1 when it starts to drain, and the next
@@ -103,9 +110,9 @@ struct vrt_ctx {
     uint32_t* drain_signal = nullptr;
     bool drain_signalled = false;  // the most recent render launch was given the signal
     unsigned gate_releases = 0;    // host releases so far (error paths, watchdog): diagnostic
-    hipStream_t rstream[2] = {nullptr, nullptr};
-    hipEvent_t ev_r[3] = {nullptr, nullptr, nullptr}, ev_t[3] = {nullptr, nullptr, nullptr}, ev_main = nullptr;
-    bool ev_t_valid[3] = {false, false, false};
+    hipStream_t rstream[VRT_MAX_STREAMS] = {};
+    hipEvent_t ev_r[VRT_MAX_SETS] = {}, ev_t[VRT_MAX_SETS] = {}, ev_main = nullptr;
+    bool ev_t_valid[VRT_MAX_SETS] = {};
     bool overlap_ready = false, overlap_failed = false;
     bool main_dirty = true;   // work other than accumulate passes was queued on the main stream since the last overlapped launch
     unsigned pipe_seq = 0;    // overlapped launches so far
@@ -306,12 +313,12 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
     ok = ok && dalloc(&c->d_mat, nvox) == hipSuccess && dalloc(&c->d_rgb, nvox * 3) == hipSuccess && dalloc(&c->d_grid, nvox) == hipSuccess;
     ok = ok && dalloc(&c->d_l0, nw0) == hipSuccess && dalloc(&c->d_l1, nw1) == hipSuccess && dalloc(&c->d_l2, nw2) == hipSuccess &&
          dalloc(&c->d_l3, 1) == hipSuccess && dalloc(&c->d_cull, 16) == hipSuccess && dalloc(&c->d_l0c, 32768) == hipSuccess && dalloc(&c->d_l0c_base, 513) == hipSuccess;
-    ok = ok && dalloc(&c->d_mats, 128 * 14) == hipSuccess && dalloc(&c->d_counters, 1) == hipSuccess && dalloc(&c->d_work, 4 * VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE) == hipSuccess;
+    ok = ok && dalloc(&c->d_mats, 128 * 14) == hipSuccess && dalloc(&c->d_counters, 1) == hipSuccess && dalloc(&c->d_work, VRT_WORK_SETS * VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE) == hipSuccess;
     ok = ok && dalloc(&c->d_cbuf[0], n) == hipSuccess && dalloc(&c->d_cbuf[1], n) == hipSuccess && dalloc(&c->d_spec_planes, n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->d_gb_pos, n) == hipSuccess;
     ok = ok && dalloc(&c->d_gb_mat, n) == hipSuccess && dalloc(&c->d_refl_planes, n * VRT_MAX_FUSED) == hipSuccess;
     if (ok) { c->d_color_s = c->d_spec_planes + (size_t)(VRT_MAX_FUSED - 1) * n; c->d_gb_refl = c->d_refl_planes + (size_t)(VRT_MAX_FUSED - 1) * n; }
     ok = ok && dalloc(&c->d_gb_refl_f, n) == hipSuccess && dalloc(&c->d_ldr, n) == hipSuccess;
-    for (int s = 0; s < 4 && ok; s++) ok = ok && dalloc(&c->d_gb_normal[s], n) == hipSuccess && dalloc(&c->d_gb_depth[s], n) == hipSuccess;
+    for (int s = 0; s < VRT_GB_ROT && ok; s++) ok = ok && dalloc(&c->d_gb_normal[s], n) == hipSuccess && dalloc(&c->d_gb_depth[s], n) == hipSuccess;
     for (int s = 0; s < 2 && ok; s++) {
         ok = ok && dalloc(&c->d_hist_d[s], n) == hipSuccess && dalloc(&c->d_hist_s[s], n) == hipSuccess;
         if (cfg->use_restir) ok = ok && dalloc(&c->d_res[s], n) == hipSuccess;
@@ -349,19 +356,30 @@ void vrt_destroy(vrt_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     release_gate(c);   // nothing may be left waiting at a gate
-    for (int s = 0; s < 2; s++) if (c->rstream[s]) hipStreamSynchronize(c->rstream[s]);
+    for (int s = 0; s < VRT_MAX_STREAMS; s++) if (c->rstream[s]) hipStreamSynchronize(c->rstream[s]);
     if (c->stream) hipStreamSynchronize(c->stream);
     resolve_events(c);
-    for (int s = 0; s < 3; s++) {
+    for (int s = 0; s < VRT_MAX_SETS; s++) {
         if (c->ev_r[s]) hipEventDestroy(c->ev_r[s]);
         if (c->ev_t[s]) hipEventDestroy(c->ev_t[s]);
     }
-    for (int s = 0; s < 2; s++) if (c->rstream[s]) hipStreamDestroy(c->rstream[s]);
+    for (int s = 0; s < VRT_MAX_STREAMS; s++) if (c->rstream[s]) hipStreamDestroy(c->rstream[s]);
     if (c->ev_main) hipEventDestroy(c->ev_main);
     if (c->drain_signal) hipFree(c->drain_signal);
-    void* ptrs[] = {c->d_prim_cache[0], c->d_prim_cache[1], c->alt_multi_d[0], c->alt_spec_planes[0], c->alt_refl_planes[0], c->alt_gb_pos[0], c->alt_gb_mat[0],
-                    c->alt_multi_d[1], c->alt_spec_planes[1], c->alt_refl_planes[1], c->alt_gb_pos[1], c->alt_gb_mat[1],
-                    c->alt_pool_scratch, c->d_gb_normal[2], c->d_gb_depth[2], c->d_gb_normal[3], c->d_gb_depth[3],
+    for (int s = 0; s < VRT_MAX_STREAMS; s++) {
+        if (c->d_prim_cache[s]) hipFree(c->d_prim_cache[s]);
+        if (s < VRT_MAX_STREAMS - 1 && c->alt_pool_scratch[s]) hipFree(c->alt_pool_scratch[s]);
+    }
+    for (int s = 0; s < VRT_MAX_SETS - 1; s++) {
+        void* copies[] = {c->alt_multi_d[s], c->alt_spec_planes[s], c->alt_refl_planes[s], c->alt_gb_pos[s], c->alt_gb_mat[s]};
+        for (void* p : copies)
+            if (p) hipFree(p);
+    }
+    for (int s = 2; s < VRT_GB_ROT; s++) {
+        if (c->d_gb_normal[s]) hipFree(c->d_gb_normal[s]);
+        if (c->d_gb_depth[s]) hipFree(c->d_gb_depth[s]);
+    }
+    void* ptrs[] = {
                     c->d_cull, c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l3, c->d_l0c, c->d_l0c_base, c->d_mats, c->d_counters, c->d_work, c->d_sky_scat,
                     c->d_sky_trans, c->d_cloud_ambient, c->d_trans_lut, c->d_cloud_tex, c->d_cbuf[0], c->d_cbuf[1], c->d_spec_planes, c->d_color_d2,
                     c->d_color_s2, c->d_gb_pos, c->d_gb_normal[0], c->d_gb_normal[1], c->d_gb_depth[0], c->d_gb_depth[1],
@@ -528,13 +546,31 @@ static bool ensure_overlap(vrt_ctx* c) {
     if (c->overlap_ready) return true;
     if (c->overlap_failed) return false;
     const size_t n = c->npix;
+    // How deep.  A launch lasts at least as long as its deepest path takes alone (about 0.2 ms at 8 bounces), whatever its
+    // size, and a workgroup slot its wave has left stays empty until the NEXT launch may start.  A launch of every slot can
+    // only be followed when it starts to drain (two in flight).  Launches of half the slots each follow one another at half
+    // that distance -- two run at full strength while a third drains and a fourth waits its turn.  Measured
+    // (profiles/r02_pipeline_depth.txt): 1080p x 4 samples +3.7 %, half of it +5 %, an eighth (one rank's rows of an 8-GPU
+    // run) +24 %; thirds and quarters of the slots are worse again; a 4K frame (33 M items a launch) loses 0-7 % and keeps
+    // the two-deep pipeline.
+    // VRT_DEEP_ITEMS: largest launch (pixels x fused samples) that gets the deep pipeline; VRT_STREAMS / VRT_GRID_DIV override.
+    size_t deep_items = (size_t)12 << 20;
+    if (const char* e = getenv("VRT_DEEP_ITEMS")) deep_items = (size_t)atoll(e);
+    const bool deep = (size_t)c->cfg.width * (size_t)(c->own1 - c->own0) * VRT_MAX_FUSED <= deep_items;
+    c->n_streams = deep ? 4 : 2;
+    c->grid_div = deep ? 2 : 1;
+    if (const char* e = getenv("VRT_STREAMS")) { const int v = atoi(e); if (v == 2 || v == 4) c->n_streams = v; }
+    if (const char* e = getenv("VRT_GRID_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 4) c->grid_div = v; }
+    const int n_sets = c->n_streams + 1;
     bool ok = true;
-    for (int s = 0; s < 2 && ok; s++)
+    for (int s = 0; s < n_sets - 1 && ok; s++)
         ok = dalloc(&c->alt_multi_d[s], n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->alt_spec_planes[s], n * VRT_MAX_FUSED) == hipSuccess &&
              dalloc(&c->alt_refl_planes[s], n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->alt_gb_pos[s], n) == hipSuccess &&
-             dalloc(&c->alt_gb_mat[s], n) == hipSuccess && hipStreamCreateWithFlags(&c->rstream[s], hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->alt_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks)) == hipSuccess;
-    for (int s = 0; s < 3 && ok; s++)
+             dalloc(&c->alt_gb_mat[s], n) == hipSuccess;
+    for (int s = 0; s < c->n_streams && ok; s++) ok = hipStreamCreateWithFlags(&c->rstream[s], hipStreamNonBlocking) == hipSuccess;
+    for (int s = 0; s < c->n_streams - 1 && ok; s++)
+        ok = hipMalloc((void**)&c->alt_pool_scratch[s], pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks)) == hipSuccess;
+    for (int s = 0; s < n_sets && ok; s++)
         ok = hipEventCreateWithFlags(&c->ev_r[s], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_t[s], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) == hipSuccess;
@@ -562,15 +598,15 @@ static void abort_pipeline(vrt_ctx* c) {
     const std::string keep = g_err;
     release_gate(c);
     c->drain_signalled = false;
-    for (int s = 0; s < 2; s++) if (c->rstream[s]) (void)hipStreamSynchronize(c->rstream[s]);
+    for (int s = 0; s < VRT_MAX_STREAMS; s++) if (c->rstream[s]) (void)hipStreamSynchronize(c->rstream[s]);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipGetLastError();
     resolve_events(c);
-    // the work heads rotate with the launch number and each launch zeroes the set two launches ahead: a launch that did not
-    // run leaves a used set behind -- nothing is in flight now, so all four start clean
-    (void)hipMemset(c->d_work, 0, 4 * VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE * sizeof(unsigned));
+    // the work heads rotate with the launch number and each launch zeroes the set eight launches ahead: a launch that did not
+    // run leaves a used set behind -- nothing is in flight now, so all of them start clean
+    (void)hipMemset(c->d_work, 0, VRT_WORK_SETS * VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE * sizeof(unsigned));
     (void)hipGetLastError();
-    c->ev_t_valid[0] = c->ev_t_valid[1] = c->ev_t_valid[2] = false;
+    for (int s = 0; s < VRT_MAX_SETS; s++) c->ev_t_valid[s] = false;
     c->main_dirty = true;
     c->render_blocks = 0;   // residency and scratch are looked at again
     g_err = keep;
@@ -613,9 +649,11 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             HIP_TRY(sync_guarded(c, c->stream));
             if (c->d_pool_scratch) { HIP_TRY(hipFree(c->d_pool_scratch)); c->d_pool_scratch = nullptr; }
             HIP_TRY(hipMalloc((void**)&c->d_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks)));
-            if (c->overlap_ready) {  // the second render stream's scratch follows
-                if (c->alt_pool_scratch) { HIP_TRY(hipFree(c->alt_pool_scratch)); c->alt_pool_scratch = nullptr; }
-                HIP_TRY(hipMalloc((void**)&c->alt_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks)));
+            if (c->overlap_ready) {  // the other render streams' scratch follows
+                for (int s = 0; s < c->n_streams - 1; s++) {
+                    if (c->alt_pool_scratch[s]) { HIP_TRY(hipFree(c->alt_pool_scratch[s])); c->alt_pool_scratch[s] = nullptr; }
+                    HIP_TRY(hipMalloc((void**)&c->alt_pool_scratch[s], pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks)));
+                }
             }
         }
     }
@@ -628,10 +666,10 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
     const bool can_fuse = !restir && c->cam.camera_is_moving == 0 && c->cam.render_scale == 1.0f;
     // A persistent render launch ends in a tail: the last paths of every wave bounce on at low occupancy (about 0.16 ms
     // of a 1.5 ms launch at 1080p).  Fused launches of the pooled kernel are therefore OVERLAPPED: launch k+1 goes to
-    // the other of two render streams and writes the other copy of the colour planes / g-buffer while launch k drains
-    // and its temporal pass (main stream, waits for launch k only) runs.  With three copies launch k+3 reuses launch
-    // k's and waits for temporal pass k, so render launches follow each other without a gap and the temporal passes
-    // run beside them.  Results are unchanged; VRT_OVERLAP=0 turns it off.
+    // the next of n_streams render streams and writes the next copy of the colour planes / g-buffer while launch k drains
+    // and its temporal pass (main stream, waits for launch k only) runs.  With n_streams + 1 copies launch k+n_streams+1
+    // reuses launch k's and waits for temporal pass k, so render launches follow each other without a gap and the temporal
+    // passes run beside them (ensure_overlap: how deep).  Results are unchanged; VRT_OVERLAP=0 turns it off.
     bool may_overlap = c->pooled && can_fuse;
     if (const char* e = getenv("VRT_OVERLAP")) { if (atoi(e) == 0) may_overlap = false; }
     for (int done = 0; done < n_samples;) {
@@ -640,19 +678,20 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             if (dalloc(&c->d_multi_d, c->npix * VRT_MAX_FUSED) != hipSuccess) { (void)hipGetLastError(); c->d_multi_d = nullptr; g = 1; }  // no memory: one launch per sample
         }
         const bool overlapped = may_overlap && g > 1 && ensure_overlap(c);
-        const int set = overlapped ? (int)(c->pipe_seq % 3u) : 0;
-        const int lane_of = (int)(c->pipe_seq & 1u);  // which render stream (and pool scratch): consecutive launches alternate
+        const int set = overlapped ? (int)(c->pipe_seq % (unsigned)(c->n_streams + 1)) : 0;
+        const int lane_of = (int)(c->pipe_seq % (unsigned)c->n_streams);  // which render stream (and pool scratch): consecutive launches take turns
         hipStream_t rs = overlapped ? c->rstream[lane_of] : c->stream;
         if (overlapped) {
             if (c->main_dirty) {  // uploads / prepare / sky kernels queued on the main stream come first
                 HIP_TRY(hipEventRecord(c->ev_main, c->stream));
-                HIP_TRY(hipStreamWaitEvent(c->rstream[0], c->ev_main, 0));
-                HIP_TRY(hipStreamWaitEvent(c->rstream[1], c->ev_main, 0));
+                for (int s = 0; s < c->n_streams; s++) HIP_TRY(hipStreamWaitEvent(c->rstream[s], c->ev_main, 0));
                 c->main_dirty = false;
             }
             if (c->ev_t_valid[set]) HIP_TRY(hipStreamWaitEvent(rs, c->ev_t[set], 0));  // the pass that last read this copy
-            if (c->drain_signal && c->drain_signalled)  // dispatch when the launch before this one starts to drain
-                HIP_TRY(hipStreamWaitValue32(rs, c->drain_signal, c->launch_seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+            // dispatch when the launch whose workgroup slots this one will take starts to drain: the one before it, or with
+            // launches of half the slots the one before that (the signal carries the number + 1 of the latest launch draining)
+            if (c->drain_signal && c->drain_signalled && c->launch_seq + 1u > (unsigned)c->grid_div)
+                HIP_TRY(hipStreamWaitValue32(rs, c->drain_signal, c->launch_seq + 1u - (unsigned)c->grid_div, hipStreamWaitValueGte, 0xFFFFFFFFu));
         } else if (c->last_set != 0) {
             // back to the single copy: whoever reads pixels this launch does not write (moving camera at half render
             // scale) expects the last sample of the last launch in the canonical buffers
@@ -695,11 +734,12 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         if (const char* e = getenv("VRT_TEST_FAIL_LAUNCH")) { if ((unsigned)atoi(e) == seq) return fail(VRT_E_DEVICE, "injected launch failure (VRT_TEST_FAIL_LAUNCH)"); }
         PrimaryRecord* prim = nullptr;  // fused samples share their camera rays through this table (vrt_pool.h)
         if (c->pooled && g > 1 && (!instr || c->count_as_timed)) {  // counting the reference's work: every camera ray is walked
-            const int which = (overlapped && lane_of) ? 1 : 0;
+            const int which = overlapped ? lane_of : 0;
             if (!c->d_prim_cache[which] && dalloc(&c->d_prim_cache[which], c->npix) != hipSuccess) { (void)hipGetLastError(); c->d_prim_cache[which] = nullptr; }
             prim = c->d_prim_cache[which];
         }
-        if (c->pooled) HIP_TRY(launch_render_pool(rs, c->cfg.grid_res, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch : c->d_pool_scratch, c->drain_signal, prim, culling(c)));
+        const int blocks = overlapped ? (c->render_blocks / c->grid_div + 7) & ~7 : c->render_blocks;  // whole rounds of the 8 XCDs
+        if (c->pooled) HIP_TRY(launch_render_pool(rs, c->cfg.grid_res, restir, instr, blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch[lane_of - 1] : c->d_pool_scratch, c->drain_signal, prim, culling(c)));
         else HIP_TRY(launch_render(rs, c->cfg.grid_res, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g));
         c->drain_signalled = c->pooled && c->drain_signal != nullptr;
         HIP_TRY(hipEventRecord(b, rs));
@@ -743,12 +783,12 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             c->ev_t_valid[set] = true;
             c->pipe_seq += 1;
         } else if (c->overlap_ready) {  // this pass used copy 0 and the single-copy buffers: later overlapped launches wait for it
-            for (int s = 0; s < 3; s++) { HIP_TRY(hipEventRecord(c->ev_t[s], c->stream)); c->ev_t_valid[s] = true; }
+            for (int s = 0; s < c->n_streams + 1; s++) { HIP_TRY(hipEventRecord(c->ev_t[s], c->stream)); c->ev_t_valid[s] = true; }
         }
         c->last_set = set;
         c->hist_in ^= 1;
         c->prev_gb = c->cur;
-        c->cur = (c->cur + 1) % 4;
+        c->cur = (c->cur + 1) % VRT_GB_ROT;
         c->cidx ^= 1;
         c->frame += (uint32_t)g;
         c->stats.path_samples += (uint64_t)g * (uint64_t)c->cfg.width * (uint64_t)(c->own1 - c->own0);
@@ -817,7 +857,7 @@ int vrt_set_stream(vrt_ctx* c, void* hip_stream) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(sync_guarded(c, c->stream));
     resolve_events(c);
-    c->ev_t_valid[0] = c->ev_t_valid[1] = c->ev_t_valid[2] = false;  // everything recorded on the old stream has completed
+    for (int s = 0; s < VRT_MAX_SETS; s++) c->ev_t_valid[s] = false;  // everything recorded on the old stream has completed
     c->main_dirty = true;
     if (c->owns_stream && c->stream) hipStreamDestroy(c->stream);
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->owns_stream = false; }

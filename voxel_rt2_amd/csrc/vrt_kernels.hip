@@ -764,10 +764,11 @@ hipError_t query_render_residency(int grid_res, bool restir, bool instr, int* bl
 
 hipError_t launch_render(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                          const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples) {
-    // four sets of heads rotate: launch k counts on set k % 4 and zeroes set (k + 2) % 4 -- launches k and k + 1 may
-    // overlap (vrt_accumulate), so neither the set in use nor the next one may be touched; set k + 1 was zeroed by launch k - 1
-    unsigned* work_counter = work_counters + (launch_seq & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);  // the fused kernel uses head 0 only
-    unsigned* next_counter = work_counters + ((launch_seq + 2u) & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
+    // sixteen sets of heads rotate: launch k counts on set k % 16 and zeroes set (k + 8) % 16 -- up to four launches are in
+    // flight together (vrt_accumulate) and none of their sets may be touched; launch k + 8 runs on launch k's stream (the
+    // pipeline is 2 or 4 streams deep), so its set is clean before it starts whatever the other streams do
+    unsigned* work_counter = work_counters + (launch_seq & 15u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);  // the fused kernel uses head 0 only
+    unsigned* next_counter = work_counters + ((launch_seq + 8u) & 15u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     dim3 g(n_blocks), b(VRT_RENDER_THREADS);
     // pixels a wave reserves per atomic: whole 8x8 tiles.  One tile keeps the tail short (measured: 192-pixel chunks
     // cost 13 % at 1080p on the sparse scene) and still cuts the atomic rate ~3x against per-refill atomics, which
@@ -791,8 +792,8 @@ size_t pool_scratch_bytes(int grid_res, bool restir, int n_blocks) {
 hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                               const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold,
                               uint32_t* drain_signal, PrimaryRecord* prim_cache, bool cull) {
-    unsigned* work_counter = work_counters + (launch_seq & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
-    unsigned* next_counter = work_counters + ((launch_seq + 2u) & 3u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
+    unsigned* work_counter = work_counters + (launch_seq & 15u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
+    unsigned* next_counter = work_counters + ((launch_seq + 8u) & 15u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     dim3 g(n_blocks), b(64 * pool_waves_per_block(grid_res));
     // the signal carries launch_seq + 1 of the latest launch that has begun to drain
     // the black-sun variant (scene.py's default light) compiles the light sample out of the shading stage
