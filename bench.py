@@ -127,8 +127,10 @@ def render_bytes(c):
     return 4.0 * c["q"] + 60.0 * c["hc"] + 96.0 * c["ls"] + 52.0
 
 
-def roofline_block(kernel, kernel_ms, units_per_launch, bytes_ref, bytes_timed, counters, notes):
-    """HBM roofline of one kernel: algorithmic bytes per launch over its measured duration."""
+def roofline_block(kernel, kernel_ms, units_per_launch, bytes_ref, bytes_timed, counters, notes, period_ms=None):
+    """HBM roofline of one kernel: algorithmic bytes per launch over its measured duration (`achieved`, `frac`: what the rocprofv3
+    kernel trace shows per launch).  Launches of this kernel overlap (up to four in flight, half of the workgroup
+    slots each), so the chip's rate is a launch's bytes over the PERIOD between launches: `all_launches_in_flight`."""
     ach = bytes_timed * units_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     ach_ref = bytes_ref * units_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     k = counters.get(kernel, {}) if counters else {}
@@ -147,6 +149,14 @@ def roofline_block(kernel, kernel_ms, units_per_launch, bytes_ref, bytes_timed, 
         blk["valu_issue"] = {"achieved": round(g, 1), "unit": "G wave-instructions/s", "peak_nominal": VALU_PEAK_NOMINAL,
                              "frac_nominal": round(g / VALU_PEAK_NOMINAL, 4), "peak_measured_2_waves_per_simd": VALU_PEAK_MEASURED_2WAVES,
                              "frac_measured": round(g / VALU_PEAK_MEASURED_2WAVES, 4)}
+    if period_ms and kernel_ms > 0:
+        k_in = kernel_ms / period_ms
+        blk["all_launches_in_flight"] = {"launch_period_ms": round(period_ms, 4), "launches_in_flight": round(k_in, 2),
+                                         "achieved": round(ach * k_in, 3), "frac": round(ach * k_in / HBM_PEAK_GBS, 6)}
+        if "valu_issue" in blk:
+            g = blk["valu_issue"]["achieved"] * k_in
+            blk["all_launches_in_flight"]["valu_issue"] = {"achieved": round(g, 1), "frac_nominal": round(g / VALU_PEAK_NOMINAL, 4),
+                                                           "frac_measured": round(g / VALU_PEAK_MEASURED_2WAVES, 4)}
     blk["note"] = notes
     return blk
 
@@ -207,11 +217,13 @@ def run_secondary(lib, case, counters):
         kernel, kms, units = "k_render_pool", ms["render"], per_launch
         b_ref, b_timed = render_bytes(work["reference"]), render_bytes(work["timed"])
         note = "unit = one path-sample; launches overlap, so the kernel duration is a launch's span and the step period is ms_per_step"
+    period = dt / steps * 1e3 / (spp if case.get("restir") else max(st["render_launches"], 1) / steps)
     return {"config": case["config"], "name": case["name"], "workload": case["workload"], "metric": "Mpath-samples/sec", "value": round(px * spp * steps / dt / 1e6, 2),
             "unit": "Mpath-samples/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "finite": hdr_ok,
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in ms.items()},
             "work_per_path_sample": {k: {a: round(b, 3) for a, b in v.items()} for k, v in work.items()},
-            "roofline": roofline_block(kernel, kms, units, b_ref, b_timed, counters.get(case["name"], {}), note)}
+            "roofline": roofline_block(kernel, kms, units, b_ref, b_timed, counters.get(case["name"], {}), note,
+                                       None if case.get("restir") else period)}
 
 
 def main():
@@ -289,10 +301,10 @@ def main():
     rows = bounds[rank]
 
     # gather plumbing: equal-sized tiles (padded to the tallest tile), torch owns the staging tensors.  The gather runs on
-    # its own stream behind an event, from one of three staging tiles, so that the next step's temporal pass (same stream as
+    # its own stream behind an event, from one of six staging tiles, so that the next step's temporal pass (same stream as
     # the tile copy) does not queue behind a collective that waits for the slowest rank.
     max_rows = max(b - a for a, b in bounds)
-    n_tiles = 3
+    n_tiles = 6   # deeper than the library's launch pipeline (four launches in flight on a shard this size)
     tiles = [torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device="cuda") for _ in range(n_tiles)]
     gathered = [torch.zeros_like(tiles[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
     host_gathered = [torch.zeros_like(tiles[0], device="cpu") for _ in range(world)] if (rehearse and gathered is not None) else None
@@ -383,7 +395,8 @@ def main():
         note = ("HBM is the bound the tier names; the 128^3 working set (8.3 MB) is cache resident and the kernel is bound by vector-instruction "
                 "issue under divergence at 2 waves per SIMD (DESIGN.md 7); `achieved` counts the bytes of the schedule that is timed (fused "
                 "samples share their camera rays: queries counted once), `reference_algorithm` the bytes the reference would move for the same "
-                "paths. Launches overlap: the duration is a launch's span, the step period is ms_per_step")
+                "paths. Launches overlap: `achieved` / `frac` use a launch's span (what the kernel trace shows), `all_launches_in_flight` the "
+                "period between launches (the chip's rate)")
         if counters_note:
             note += "; " + counters_note
         out = {
@@ -393,12 +406,13 @@ def main():
             "config": {"workload": "example1-style scene S1 (scenes.scene_s1), 128^3 grid, 1920x1080, 4 spp/step, 8 bounces, "
                                    "static camera, ReSTIR off", "width": WIDTH, "height": HEIGHT, "spp_per_step": SPP_PER_STEP,
                        "max_depth": MAX_DEPTH, "seed": SEED, "build_id": lib.vrt_build_id().decode(),
-                       "launch_pipeline": {"overlapped": bool(flags & 1), "dispatch_gate": bool(flags & 2), "gate_host_releases": int(flags >> 8)},
+                       "launch_pipeline": {"overlapped": bool(flags & 1), "dispatch_gate": bool(flags & 2), "gate_host_releases": int(flags >> 8),
+                                           "launches_in_flight": int((flags >> 2) & 7), "workgroup_slots_per_launch": f"1/{max(int((flags >> 5) & 7), 1)}"},
                        "sharding": (f"{world} contiguous row tiles, boundaries balanced by measured tile cost, RCCL gather per step, "
                                     f"{parallel.reserved_cus(world)} CUs' worth of workgroup slots left free for the collective; "
                                     f"tile rows {[b - a for a, b in bounds]}") if world > 1 else "none"},
             "roofline": roofline_block(render_kernel, avg_ms, samples_per_launch, render_bytes(work["reference"]), render_bytes(work["timed"]),
-                                       counters.get("config2_s1_1080p", {}), note),
+                                       counters.get("config2_s1_1080p", {}), note, elapsed / launches * 1e3),
             "work_per_path_sample": {k: {a: round(b, 3) for a, b in v.items()} for k, v in work.items()},
             "kernel_ms_per_launch": {"render": round(avg_ms, 4), "temporal": round(st["temporal_ms"] / max(st["temporal_launches"], 1), 4)},
         }

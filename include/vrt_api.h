@@ -91,6 +91,8 @@ typedef struct vrt_stats {
     uint32_t pipeline_flags;      /* bit 0: launches of consecutive vrt_accumulate calls overlap; bit 1: the next launch's dispatch
                                      is held until the running one starts to drain (stream wait on a kernel-raised word; left out
                                      where a self-test finds that queue operations are serialised, e.g. under rocprofv3 --pmc);
+                                     bits 2..4: render launches the pipeline keeps in flight (2 or 4; 0 while not overlapped);
+                                     bits 5..7: a launch takes 1 / this many of the workgroup slots (1 or 2);
                                      bits 8..31: times the host released that wait (error paths, synchronisation watchdog) */
 } vrt_stats;
 

@@ -34,6 +34,8 @@ CASES = [
 
 
 def run(case):
+    if os.environ.get("VRT_BENCH_STEPS"):   # longer runs: a deep launch pipeline takes a few steps to fill and to drain
+        case = dict(case, steps=int(os.environ["VRT_BENCH_STEPS"]))
     lib = _lib.load()
     mat, rgb, params = scenes.SCENES[case["scene"]](12345 if case["scene"] == "dense" else 0)
     sky_res = case.get("sky_res", 0)
@@ -68,8 +70,11 @@ def run(case):
     s.sync()
     lib.vrt_reset_stats(C.c_void_p(s._ctx))
     t0 = time.perf_counter()
+    sync_each = bool(os.environ.get("VRT_BENCH_SYNC_EACH"))   # a caller that looks at every frame: no two launches in flight
     for _ in range(case["steps"]):
         s.accumulate(case["spp"])
+        if sync_each:
+            s.sync()
     s.sync()
     dt = time.perf_counter() - t0
     st = s.stats()

@@ -117,6 +117,7 @@ struct vrt_ctx {
     bool main_dirty = true;   // work other than accumulate passes was queued on the main stream since the last overlapped launch
     unsigned pipe_seq = 0;    // overlapped launches so far
     int last_set = 0;         // copy (0 = the canonical buffers) the most recent render launch wrote
+    int last_render_set = -1; // copy whose ev_r the most recent overlapped launch recorded (-1: none yet)
     int hist_in = 0;  // history ping-pong
     mat4 prev_view{}, prev_proj{};
     uint32_t frame = 0;
@@ -738,7 +739,12 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             if (!c->d_prim_cache[which] && dalloc(&c->d_prim_cache[which], c->npix) != hipSuccess) { (void)hipGetLastError(); c->d_prim_cache[which] = nullptr; }
             prim = c->d_prim_cache[which];
         }
-        const int blocks = overlapped ? (c->render_blocks / c->grid_div + 7) & ~7 : c->render_blocks;  // whole rounds of the 8 XCDs
+        // A launch of half the slots only pays with other launches beside it: one that finds the pipeline empty (the caller
+        // fetches every frame, or this is the first of a run) takes every slot like a launch that is not overlapped.
+        bool lone = !overlapped;
+        if (overlapped && c->grid_div > 1) lone = c->last_render_set < 0 || hipEventQuery(c->ev_r[c->last_render_set]) == hipSuccess;
+        (void)hipGetLastError();   // (hipErrorNotReady is the expected answer)
+        const int blocks = lone ? c->render_blocks : (c->render_blocks / c->grid_div + 7) & ~7;  // whole rounds of the 8 XCDs
         if (c->pooled) HIP_TRY(launch_render_pool(rs, c->cfg.grid_res, restir, instr, blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch[lane_of - 1] : c->d_pool_scratch, c->drain_signal, prim, culling(c)));
         else HIP_TRY(launch_render(rs, c->cfg.grid_res, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g));
         c->drain_signalled = c->pooled && c->drain_signal != nullptr;
@@ -746,6 +752,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         if (overlapped) {
             HIP_TRY(hipEventRecord(c->ev_r[set], rs));
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_r[set], 0));
+            c->last_render_set = set;
         }
         const f3* cd = out.color_d;
         const f3* cs = out.color_s;
@@ -910,7 +917,8 @@ int vrt_get_stats(vrt_ctx* c, vrt_stats* out) {
     HIP_TRY(hipMemcpy(&h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     c->stats.rays = h.rays; c->stats.dda_iters = h.iters; c->stats.occupancy_queries = h.queries;
     c->stats.closest_hits = h.closest_hits; c->stats.sky_lookups = h.sky_lookups;
-    c->stats.pipeline_flags = (c->overlap_ready ? 1u : 0u) | (c->drain_signal ? 2u : 0u) | ((uint32_t)c->gate_releases << 8);
+    c->stats.pipeline_flags = (c->overlap_ready ? 1u : 0u) | (c->drain_signal ? 2u : 0u) | ((uint32_t)c->gate_releases << 8) |
+                              (c->overlap_ready ? ((uint32_t)c->n_streams << 2) | ((uint32_t)c->grid_div << 5) : 0u);
     *out = c->stats;
     return VRT_OK;
 }

@@ -239,6 +239,7 @@ VRT_DEV PrimaryRecord primary_record(const SlotRef& s, uint32_t tag) {
     return r;
 }
 VRT_DEV bool primary_record_valid(const PrimaryRecord& r, uint32_t tag) { return r.w == primary_check(r, tag); }
+#if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned int vrt_u32x4 __attribute__((ext_vector_type(4)));
 VRT_DEV void primary_record_store(PrimaryRecord* at, const PrimaryRecord& r) {  // two 16-byte stores
     const vrt_u32x4 a = {r.x, r.y, r.z, r.dx}, b = {r.dy, r.dz, r.ft, r.w};
@@ -250,6 +251,10 @@ VRT_DEV PrimaryRecord primary_record_load(const PrimaryRecord* at) {  // two 16-
     r.x = a.x; r.y = a.y; r.z = a.z; r.dx = a.w; r.dy = b.x; r.dz = b.y; r.ft = b.z; r.w = b.w;
     return r;
 }
+#else   // host builds of this header (tests/emul)
+VRT_DEV void primary_record_store(PrimaryRecord* at, const PrimaryRecord& r) { *at = r; }
+VRT_DEV PrimaryRecord primary_record_load(const PrimaryRecord* at) { return *at; }
+#endif
 template <int G>
 VRT_DEV int pool_begin_known(const FrameParams& fp, const SlotRef& s, int u, int v, int sample, const PrimaryRecord& rec) {
     Path<false> p;
