@@ -70,11 +70,14 @@ def run(case):
     s.sync()
     lib.vrt_reset_stats(C.c_void_p(s._ctx))
     t0 = time.perf_counter()
+    fetch_each = bool(os.environ.get("VRT_BENCH_FETCH_EACH"))  # the PCIe-inclusive rate: the HDR frame copied to host memory after every step
     sync_each = bool(os.environ.get("VRT_BENCH_SYNC_EACH"))   # a caller that looks at every frame: no two launches in flight
     for _ in range(case["steps"]):
         s.accumulate(case["spp"])
         if sync_each:
             s.sync()
+        if fetch_each:
+            s.fetch_hdr()
     s.sync()
     dt = time.perf_counter() - t0
     st = s.stats()
