@@ -93,3 +93,28 @@ def test_restir_row_shards_equal_full_frame():
     orc.setup(o, mat, rgb, params)
     o.accumulate(2)
     assert np.array_equal(full.view(np.uint32), o.fetch_hdr().view(np.uint32))
+
+
+@pytest.mark.parametrize("W,H,depth,rows", [(4096, 16, 4, None), (4104, 16, 4, None), (96, 64, 15, None), (96, 64, 16, None),
+                                            (640, 4100, 3, (4090, 4100))])
+def test_limits_of_the_pooled_kernel(W, H, depth, rows):
+    """The pooled kernel packs pixel coordinates in 12 bits each and the path depth in 4 (vrt_pool.h, pack_ids): frames up to
+    4096 x 4096 and 15 bounces.  At the limits (column 4095; depth 15) it must still equal the oracle; one step beyond
+    (4104 columns; rows 4090-4099 of a 4100-row frame; 16 bounces) the library falls back to the one-path-per-lane kernel
+    by itself and must equal it too."""
+    mat, rgb, params = scenes.scene_sunlit(0)
+    kw = dict(voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=depth, seed=3)
+    if rows:
+        kw["rows"] = rows
+    g, o = NativeSession(_lib.load(), "vrt_", host.make_config(W, H, **kw)), orc.Oracle(host.make_config(W, H, **kw), threads=16)
+    for s in (g, o):
+        orc.setup(s, mat, rgb, params)
+        s.accumulate(4)
+        s.accumulate(2)
+    r0, r1 = rows or (0, H)
+    a, b = g.fetch_hdr()[r0:r1], o.fetch_hdr()[r0:r1]
+    assert np.isfinite(a).all() and a.mean() > 0.0
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a != b).sum()} of {a.size} values differ"
+    for which in (_abi.BUF_GBUF_DEPTH, _abi.BUF_GBUF_NORMAL, _abi.BUF_GBUF_MAT):
+        assert np.array_equal(g.fetch_buffer(which)[r0:r1].view(np.uint8), o.fetch_buffer(which)[r0:r1].view(np.uint8)), which
+    g.close(); o.close()
