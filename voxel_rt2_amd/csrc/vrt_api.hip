@@ -89,18 +89,19 @@ struct vrt_ctx {
     float* d_mats_x = nullptr;       // [128][8] mat_derive() of every material row
     int cur = 0;      // g-buffer rotation: render writes [cur], temporal reads [prev_gb] as "prev"
     int prev_gb = VRT_GB_ROT - 1;  // the copy the most recent launch wrote
-    // Overlapped launches (vrt_accumulate): VRT_SETS copies (set 0 = the canonical buffers, alt_*[s - 1] the others) of
-    // everything a render launch writes and its temporal pass reads, two render streams and the events that order
-    // them, so that launch k+1 starts while launch k drains and temporal pass k runs beside launch k+1.
+    // Overlapped launches (vrt_accumulate): n_streams + 1 copies (set 0 = the canonical buffers, alt_*[s - 1] the others) of
+    // everything a render launch writes and its temporal pass reads, n_streams render streams and the events that order
+    // them, so that the next launches start while launch k drains and temporal pass k runs beside them.
     f3* alt_multi_d[VRT_MAX_SETS - 1] = {}; f3* alt_spec_planes[VRT_MAX_SETS - 1] = {}; float* alt_refl_planes[VRT_MAX_SETS - 1] = {};
     f3* alt_gb_pos[VRT_MAX_SETS - 1] = {}; uint32_t* alt_gb_mat[VRT_MAX_SETS - 1] = {};
     uint32_t* alt_pool_scratch[VRT_MAX_STREAMS - 1] = {};  // the other render streams' scratch
     int n_streams = 2;   // depth of the launch pipeline (ensure_overlap): 2, or 4 with launches of half the workgroups each
     int grid_div = 1;    // an overlapped launch takes render_blocks / grid_div workgroups
-    // A render launch queued behind another on the other render stream would be dispatched at once and sit in the
+    // A render launch queued behind another on another render stream would be dispatched at once and sit in the
     // queue until workgroups retire -- which the profiler and the events count as its run time.  Instead the kernel
-    // raises this word (HSA signal memory, host visible) to launch_seq + 1 when it starts to drain, and the next
-    // launch's stream waits for that value (hipStreamWaitValue32) before the dispatch.  The gate only TIMES dispatches
+    // raises this word (HSA signal memory, host visible) to launch_seq + 1 when it starts to drain, and the stream of the
+    // launch that will take its workgroup slots (the next one; the one after with half-size launches) waits for that
+    // value (hipStreamWaitValue32) before the dispatch.  The gate only TIMES dispatches
     // (ordering is by events), so raising the word early is always safe: release_gate() does it from the host on
     // error paths and when a synchronisation overstays (gate_watchdog_ms).  A stream wait is itself a queue operation:
     // under a tool that runs one queue operation at a time (rocprofv3 --pmc) a wait that is dispatched ahead of the
@@ -161,7 +162,7 @@ static hipError_t sync_guarded(vrt_ctx* c, hipStream_t st) {
     return hipStreamSynchronize(st);
 }
 
-// True when a stream wait queued BEFORE the operation that satisfies it (on the other render stream) completes: the
+// True when a stream wait queued BEFORE the operation that satisfies it (on another render stream) completes: the
 // order in which a launch and the wait of its successor can reach the hardware.  Under a tool that serialises queue
 // operations it does not -- then the word is released from the host and the caller leaves the gate out.
 static bool gate_self_test(vrt_ctx* c) {

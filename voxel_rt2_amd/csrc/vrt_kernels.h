@@ -21,7 +21,7 @@
 // One word saturates near 88 pulls/us chip-wide and answers in ~3 us with 256 CUs pulling (MI355X_MICROARCH.md, row
 // `dequeue`), so the pooled kernel splits the items into VRT_WORK_HEADS contiguous ranges, one head per XCD on a
 // 128-byte line of its own; a wave pulls from the head of its XCD and moves on to the next head when that range is
-// used up.  Two sets of heads alternate between launches (a launch zeroes the set the next one will use).
+// used up.  Sixteen sets of heads rotate with the launch number (a launch zeroes the set eight launches ahead: vrt_kernels.hip).
 #define VRT_WORK_HEADS 8
 #define VRT_WORK_HEAD_STRIDE 32    // uints between heads
 #ifndef VRT_POOL_WAVES

@@ -205,19 +205,18 @@ VRT_DEV int pool_launch_ray(const FrameParams& fp, const float* cull, const Slot
 
 // The samples fused into one launch share camera and jitter, so a pixel's camera ray -- three quarters of all DDA
 // steps on the sparse scene -- and its whole closest-hit record are the same for all of them.  The path of sample 0
-// leaves the record (distance, cell, normal code; tagged with the launch) in a per-pixel table when its walk ends;
-// work items are ordered sample-major within a work range, so by the time a pixel's later samples begin, the
-// record is there and they start at SHADE / ESCAPE without setting up or walking a ray.  A missing or stale record
-// just means the ray is walked as usual.  Writer and reader are different CUs with no fence between them (a release /
-// acquire pair costs microseconds, MI355X_MICROARCH.md: this is per ray), so nothing is ASSUMED about how the 16 bytes
-// arrive: the fourth word is the launch tag mixed with a hash of the three payload words, and a reader accepts a record
-// only if that word matches the payload it read and the launch it runs in.  A stale record (other launch), a missing one
-// and a torn one -- words of two different stores -- all fail the check (a tear passes with probability 2^-32) and the
-// ray is walked.  The record is still written and read with one 16-byte instruction each (observed untorn on gfx950).
-// The record also carries what every sample of the pixel would work out again before it could use the hit: the ray's
+// leaves the record (distance, cell, normal code; tagged with the launch) in a per-pixel table when its walk ends -- or in
+// BEGIN, when there was nothing to walk; work items are ordered sample-major within a work range, so by the time a pixel's
+// later samples begin, the record is there and they start at SHADE / ESCAPE without setting up or walking a ray.  The
+// record also carries what every sample of the pixel would work out again before it could use the hit: the ray's
 // direction (camera_ray_dir: a matrix, a perspective divide and a normalisation -- 15 correctly rounded divisions and a
-// square root) and its floor distance (floor_probe), as the bits sample 0 computed.  Two 16-byte halves; the check word
-// covers all seven payload words, so halves of two different stores fail it like any other tear.
+// square root) and its floor distance (floor_probe), as the bits sample 0 computed.  A missing or stale record just
+// means the ray is set up and walked as usual.  Writer and reader are different CUs with no fence between them (a release /
+// acquire pair costs microseconds, MI355X_MICROARCH.md: this is per ray), so nothing is ASSUMED about how the 32 bytes
+// (two 16-byte stores, two 16-byte loads) arrive: the last word is the launch tag mixed with a hash of the seven payload
+// words, and a reader accepts a record only if that word matches the payload it read and the launch it runs in.  A stale
+// record (other launch), a missing one and a torn one -- words of two different stores, or halves of them -- all fail the
+// check (a tear passes with probability 2^-32) and the ray is walked.
 struct alignas(16) PrimaryRecord { uint32_t x, y, z, dx, dy, dz, ft, w; };  // PF_T, PF_CELL_XY, PF_CELL_Z, PF_DIR[3], PF_FLOOR_T, check word
 VRT_DEV uint32_t primary_check(const PrimaryRecord& r, uint32_t tag) {
     uint32_t h = r.x * 0x9E3779B1u;
