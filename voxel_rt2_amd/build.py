@@ -19,6 +19,11 @@ FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-fno-gpu-flush-denormals-to-zero",
+    # no v_pk_{mul,add,fma}_f32: the two-lane forms need their operands in aligned register pairs, and the moves and the register
+    # pressure that buys cost more than the halved issue count saves -- the render kernels spill 16-17 registers with them and
+    # none without (same IEEE results per component; config 2 +6 %, sun-lit +6 %, config 3 +4 %, dense 4K +1.5 %).  The host
+    # pass ignores the feature name with a warning.
+    "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
     "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result",
 ]
 
