@@ -131,7 +131,12 @@ struct vrt_ctx {
 template <class T>
 static hipError_t dalloc(T** p, size_t n) {
     hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    // hipMemset fills on the NULL stream and may return before the fill has run; the context's streams are non-blocking, so
+    // nothing orders a launch queued next (a buffer allocated on its first use: the fused samples' planes) after that fill --
+    // it zeroed the first tiles a render launch had just written (seen once the allocator handed back recycled memory:
+    // tests/test_gpu_parity.py::test_row_shards_equal_full_frame after the large frames of test_gpu_fullsize.py).  Wait for it.
     if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(T));
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     return e;
 }
 
@@ -607,6 +612,7 @@ static void abort_pipeline(vrt_ctx* c) {
     // the work heads rotate with the launch number and each launch zeroes the set eight launches ahead: a launch that did not
     // run leaves a used set behind -- nothing is in flight now, so all of them start clean
     (void)hipMemset(c->d_work, 0, VRT_WORK_SETS * VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE * sizeof(unsigned));
+    (void)hipStreamSynchronize(nullptr);   // (the fill runs on the NULL stream: see dalloc)
     (void)hipGetLastError();
     for (int s = 0; s < VRT_MAX_SETS; s++) c->ev_t_valid[s] = false;
     c->main_dirty = true;
@@ -928,7 +934,8 @@ int vrt_reset_stats(vrt_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(sync_guarded(c, c->stream));
     resolve_events(c);
-    HIP_TRY(hipMemset(c->d_counters, 0, sizeof(Counters)));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), c->stream));   // on the stream the counting launches follow on
+    c->main_dirty = true;
     memset(&c->stats, 0, sizeof(c->stats));
     return VRT_OK;
 }
