@@ -61,6 +61,17 @@ def main():
                                   ("k_render", "vrt::k_render<", 2), ("k_gris", "vrt::k_gris<", 1),
                                   ("k_gris_prepare", "vrt::k_gris_prepare", None), ("k_temporal", "vrt::k_temporal", None)):
             k, v = pick(m, prefix, ia)
+            if v and short == "k_gris":
+                # the spatial-reuse pass runs as two kernels (template argument 3 = 1, 2: vrt_restir.h): one entry, their counters summed
+                halves = [(kk, vv) for kk, vv in m.items() if kk.replace("void ", "").startswith(prefix)
+                          and [a_.strip() for a_ in kk.split("<")[1].rstrip(">").split(",")][ia] != "true"]
+                if len(halves) > 1:
+                    names = sorted(kk for kk, _ in halves)
+                    summed = {}
+                    for _, vv in halves:
+                        for c_, x in vv.items():
+                            summed[c_] = summed.get(c_, 0.0) + x
+                    k, v = " + ".join(names), summed
             if v:
                 ent[short] = dict(entry(v), kernel=k)
         out["kernels"][name] = ent

@@ -608,11 +608,18 @@ __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attr
 }
 
 // ---- spatial reuse ---------------------------------------------------------------------------
-template <int G, bool INSTR>
-#ifndef VRT_GRIS_MIN_WAVES
-#define VRT_GRIS_MIN_WAVES 2   // 256 registers, no spills; one wave per SIMD left the VALU idle a third of the time (6.6 vs 10.2 ms)
+#ifndef VRT_GRIS_SPLIT
+#define VRT_GRIS_SPLIT 1   // the pass as two kernels of three waves per SIMD each (gris_pixel, vrt_restir.h); 0: one kernel of two
+                           // (config 3: 358 against 317 Mpath-samples/s; the first half alone at three waves: 335)
 #endif
-__global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES) void k_gris(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r_first, int r1, int tiles_x, int band_w) {
+#ifndef VRT_GRIS_MIN_WAVES
+#define VRT_GRIS_MIN_WAVES 2   // whole pass: 256 registers, no spills; one wave per SIMD left the VALU idle a third of the time (6.6 vs 10.2 ms)
+#endif
+#ifndef VRT_GRIS_MIN_WAVES_B
+#define VRT_GRIS_MIN_WAVES_B 3 // second half: 168 registers hold it once the output reservoir carries the chosen TAP instead of its sample
+#endif
+template <int G, bool INSTR, int PHASE = 0>
+__global__ __launch_bounds__(256, (PHASE == 1 ? 3 : PHASE == 2 ? VRT_GRIS_MIN_WAVES_B : VRT_GRIS_MIN_WAVES)) void k_gris(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r_first, int r1, int tiles_x, int band_w) {
     constexpr int N1 = GridDim<G>::n1 * GridDim<G>::n1 * GridDim<G>::n1, N2 = GridDim<G>::n2 * GridDim<G>::n2 * GridDim<G>::n2;
     __shared__ unsigned long long s_l1[N1];
     __shared__ unsigned long long s_l2[N2];
@@ -650,7 +657,7 @@ __global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES) void k_gris(FrameParams fp
     taps.cs = s_cs[wave]; taps.off = &s_off[0][threadIdx.x]; taps.off_stride = 256;
     TraceStats ts;
     stats_zero(ts);
-    if (bx < tiles_x && u < fp.W && v >= r_first && v < r1) gris_pixel(fp, scl, P, gbl, taps, u, v, 0, 24.0f, 32, 1, ts);
+    if (bx < tiles_x && u < fp.W && v >= r_first && v < r1) gris_pixel<PHASE>(fp, scl, P, gbl, taps, u, v, 0, 24.0f, 32, 1, ts);
     if (INSTR) flush_stats(ts, sc.counters);
 }
 
@@ -822,7 +829,12 @@ hipError_t launch_gris(hipStream_t st, int grid_res, bool instr, const FramePara
     const int ra = r0 & ~7;
     const int tiles_x = (fp.W + 15) / 16, tiles_y = (r1 - ra + 15) / 16, band_w = (tiles_x + 7) / 8;
     dim3 g(8 * band_w * tiles_y), b(256);
+#if VRT_GRIS_SPLIT
+    VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_gris<G, A, 1>), g, b, 0, st, fp, sc, gb, ra, r0, r1, tiles_x, band_w)));
+    VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_gris<G, A, 2>), g, b, 0, st, fp, sc, gb, ra, r0, r1, tiles_x, band_w)));
+#else
     VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_gris<G, A>), g, b, 0, st, fp, sc, gb, ra, r0, r1, tiles_x, band_w)));
+#endif
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }

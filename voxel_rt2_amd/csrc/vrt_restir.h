@@ -380,7 +380,12 @@ VRT_DEV bool gris_tap(const FrameParams& fp, const GrisTaps& taps, int u, int v,
 }
 
 // pathtracer.py:815-989, called as spatial_GRIS(0, 24.0, 32, 1) (:1313)
-template <class PyrT>
+// PHASE 0: the whole pass.  PHASE 1 / 2: the pass as two kernels -- the tap test and the canonical MIS weight (first two
+// loops), which leave the mask of accepted taps and the weight in the pixel's own GrisGeo record (pad, pad3: nobody else reads
+// those words); then the resampling loop and everything after it.  Each half carries only its own loop invariants (the
+// centre's sample in the first, its shading point and the output reservoir in the second), which is what lets each fit the
+// 168 registers of a third wave per SIMD (the whole pass needs about 250).  Same arithmetic in the same order.
+template <int PHASE = 0, class PyrT>
 VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& P, const GrisBuffers& gb, const GrisTaps& taps, int u, int v,
                         int pass_id, float max_radius, int max_taps, int pass_total, TraceStats& ts) {
     const int idx = (v - fp.row0) * fp.W + u;
@@ -389,7 +394,7 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         // last HDR value there (it swaps roles with the HDR target every pass): carry it across.  Specular: what the
         // reference still has there is the LAST PASS'S RESULT OF THIS KERNEL, which is exactly what the output buffer
         // still holds -- leave it (copying the input would bring back the last render output from before its reuse).
-        gb.color_d_out[idx] = gb.color_d_in[idx];
+        if (PHASE != 1) gb.color_d_out[idx] = gb.color_d_in[idx];
         return;
     }
     dm_rng rng = dm_rng_init(fp.seed, fp.frame, (uint32_t)(v * fp.W + u), 1u);
@@ -407,6 +412,7 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     const float cdist = cg.dist;
     const f3 cn1 = cg.n;
     if (near_zero3(cx1)) {
+        if (PHASE == 1) return;
         gb.color_d_out[idx] = center.z.F;
         gb.color_s_out[idx] = gb.color_s_in[idx];
         gb.res_out[idx] = gb.res_in[idx];
@@ -415,6 +421,7 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     int valid = 0;
     float canonical_mis = 1.0f;
     f3 chosen_d = mk3(0.0f), chosen_s = mk3(0.0f);
+    int chosen_tap = -1;   // (second kernel of the split pass: the tap whose sample the output reservoir holds)
 
     // The reference's tap loop does two independent things per accepted tap: (1) shift the CENTRE sample into the
     // neighbour's domain to grow the canonical MIS weight (:917-931), (2) shift the NEIGHBOUR's sample into the centre's
@@ -425,7 +432,8 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     // each pixel's OWN accepted taps (ascending, so the order of sums and draws is the reference's): a wave runs as many
     // trips as its busiest pixel accepted taps instead of all 32 with the rejected pixels' lanes idle.
     unsigned accepted = 0u;  // max_taps <= 32
-    for (int i = 0; i < max_taps; i++) {
+    if (PHASE == 2) { accepted = cg.pad; canonical_mis = dm_u2f(cg.pad3); }
+    for (int i = 0; PHASE != 2 && i < max_taps; i++) {
         int tx, ty;
         if (!gris_tap(fp, taps, u, v, i, radius_shift, max_radius, max_taps, tx, ty)) continue;
         taps.off[i * taps.off_stride] = (uint16_t)((tx - u + 128) | ((ty - v + 128) << 8));  // |offset| <= max_radius < 128
@@ -435,7 +443,7 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         if (dm_abs(ndist - cdist) > 0.1f * cdist || dot3(cn1, nn1) < 0.5f) continue;  // :912
         accepted |= 1u << i;
     }
-    for (unsigned m = accepted; m != 0u; m &= m - 1u) {
+    for (unsigned m = (PHASE == 2) ? 0u : accepted; m != 0u; m &= m - 1u) {
         const int i = __builtin_ctz(m);
         const int packed = taps.off[i * taps.off_stride];
         const int tx = u + (packed & 255) - 128, ty = v + (packed >> 8) - 128;
@@ -459,6 +467,11 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     // Register budget (the kernel is held to 256 and waits on spill reloads): the first tap loop carries the centre's sample,
     // the second the centre's shading point and the output reservoir -- neither needs the other's, so the shading point is
     // built only now and the centre's sample is read again after the second loop instead of being kept across it.
+    if (PHASE == 1) {   // what the second kernel needs of the first
+        gb.geo[idx].pad = accepted;
+        gb.geo[idx].pad3 = dm_f2u(canonical_mis);
+        return;
+    }
     const float center_M = center.M;
     int cmat_id;
     const Material cmat = material_from_bits(sc.mats, cg.mat, cmat_id);
@@ -468,8 +481,12 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     cdsc.lambert = cg.lambert; cdsc.sheen_col = cg.sheen_col; cdsc.spec_col = cg.spec_col; cdsc.fv = cg.fv; cdsc.g_v = cg.g_v; cdsc.gc_v = cg.gc_v;
     for (unsigned m = accepted; m != 0u; m &= m - 1u) {
         const int i = __builtin_ctz(m);
-        const int packed = taps.off[i * taps.off_stride];
-        const int tx = u + (packed & 255) - 128, ty = v + (packed >> 8) - 128;
+        int tx, ty;
+        if (PHASE == 2) (void)gris_tap(fp, taps, u, v, i, radius_shift, max_radius, max_taps, tx, ty);   // (the first kernel's table of offsets is gone)
+        else {
+            const int packed = taps.off[i * taps.off_stride];
+            tx = u + (packed & 255) - 128; ty = v + (packed >> 8) - 128;
+        }
         Reservoir nb;
         f3 nb_rc_ty, nb_sky_t;
         RcPre nb_pre;
@@ -485,8 +502,31 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         if (dm_isinf(nw) || dm_isnan(nw)) nw = 0.0f;
 
         nb.z.F = sd + ss;
-        if (reservoir_add(outr, nb.z, nb.M, nb.weight * p_hat * jac * nw, rng, false)) { chosen_d = sd; chosen_s = ss; }
+        bool sel;
+        if (PHASE == 2) {
+            // reservoir_add() without the copy of the sample: the second kernel remembers WHICH tap the reservoir holds and
+            // reads that sample again after the loop (its record is one load away; carried through the loop it is 17 registers)
+            const float in_w = nb.weight * p_hat * jac * nw;
+            outr.M += nb.M;
+            sel = false;
+            if (in_w > 0.0f) {
+                outr.weight += in_w;
+                sel = dm_rng_f32(&rng) * outr.weight <= in_w;
+                if (sel) chosen_tap = i;
+            }
+        } else sel = reservoir_add(outr, nb.z, nb.M, nb.weight * p_hat * jac * nw, rng, false);
+        if (sel) { chosen_d = sd; chosen_s = ss; }
         valid += 1;
+    }
+    if (PHASE == 2 && chosen_tap >= 0) {
+        int tx, ty;
+        (void)gris_tap(fp, taps, u, v, chosen_tap, radius_shift, max_radius, max_taps, tx, ty);
+        Reservoir nb;
+        f3 nb_rc_ty, nb_sky_t;
+        RcPre nb_pre;
+        gris_load_src(nb, nb_rc_ty, nb_sky_t, nb_pre, gb.src[(ty - fp.row0) * fp.W + tx]);
+        outr.z = nb.z;
+        outr.z.F = chosen_d + chosen_s;
     }
 
 #if defined(__HIP_DEVICE_COMPILE__)
