@@ -84,6 +84,7 @@ struct vrt_ctx {
     f4 *d_hist_d[2] = {nullptr, nullptr}, *d_hist_s[2] = {nullptr, nullptr};
     f4* d_ldr = nullptr;
     ReservoirRec* d_res[2] = {nullptr, nullptr};
+    ReservoirRec* d_res_planes = nullptr;   // input reservoirs: VRT_MAX_FUSED planes, d_res[0] is the last of them
     GrisGeo* d_gris_geo = nullptr;   // per-pixel records of k_gris's prepare pass (vrt_restir.h)
     GrisSrc* d_gris_src = nullptr;
     float* d_mats_x = nullptr;       // [128][8] mat_derive() of every material row
@@ -328,7 +329,12 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
     for (int s = 0; s < VRT_GB_ROT && ok; s++) ok = ok && dalloc(&c->d_gb_normal[s], n) == hipSuccess && dalloc(&c->d_gb_depth[s], n) == hipSuccess;
     for (int s = 0; s < 2 && ok; s++) {
         ok = ok && dalloc(&c->d_hist_d[s], n) == hipSuccess && dalloc(&c->d_hist_s[s], n) == hipSuccess;
-        if (cfg->use_restir) ok = ok && dalloc(&c->d_res[s], n) == hipSuccess;
+    }
+    if (cfg->use_restir) {
+        // VRT_MAX_FUSED planes of input reservoirs, the LAST being the slot the reference knows (as with the specular planes):
+        // a fused launch ends on it, so a later pass that renders part of the frame finds the last sample's reservoirs there
+        ok = ok && dalloc(&c->d_res_planes, n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->d_res[1], n) == hipSuccess;
+        if (ok) c->d_res[0] = c->d_res_planes + (size_t)(VRT_MAX_FUSED - 1) * n;
     }
     if (cfg->use_restir) ok = ok && dalloc(&c->d_color_d2, n) == hipSuccess && dalloc(&c->d_color_s2, n) == hipSuccess &&
                               dalloc(&c->d_gris_geo, n) == hipSuccess && dalloc(&c->d_gris_src, n) == hipSuccess;
@@ -391,7 +397,7 @@ void vrt_destroy(vrt_ctx* c) {
                     c->d_sky_trans, c->d_cloud_ambient, c->d_trans_lut, c->d_cloud_tex, c->d_cbuf[0], c->d_cbuf[1], c->d_spec_planes, c->d_color_d2,
                     c->d_color_s2, c->d_gb_pos, c->d_gb_normal[0], c->d_gb_normal[1], c->d_gb_depth[0], c->d_gb_depth[1],
                     c->d_gb_mat, c->d_refl_planes, c->d_gb_refl_f, c->d_hist_d[0], c->d_hist_d[1], c->d_hist_s[0], c->d_hist_s[1],
-                    c->d_ldr, c->d_res[0], c->d_res[1], c->d_multi_d, c->d_pool_scratch, c->d_gris_geo, c->d_gris_src, c->d_mats_x};
+                    c->d_ldr, c->d_res[1], c->d_res_planes, c->d_multi_d, c->d_pool_scratch, c->d_gris_geo, c->d_gris_src, c->d_mats_x};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (c->stream && c->owns_stream) hipStreamDestroy(c->stream);
@@ -671,14 +677,19 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
     // colour planes, and ONE k_temporal launch advances the running means sample by sample in registers.
     int max_fused = VRT_MAX_FUSED;
     if (const char* e = getenv("VRT_FUSE")) { int v = atoi(e); if (v >= 1 && v <= VRT_MAX_FUSED) max_fused = v; }
-    const bool can_fuse = !restir && c->cam.camera_is_moving == 0 && c->cam.render_scale == 1.0f;
+    // With ReSTIR on the samples fuse in the RENDER launch all the same (one reservoir plane per sample beside the colour
+    // planes; the pooled kernel only): spatial reuse and accumulation then run sample by sample over the planes, as the
+    // reference runs them -- the reuse pass of a sample reads nothing an earlier sample's pass wrote.  VRT_FUSE_RESTIR=0: off.
+    bool fuse_restir = c->pooled;
+    if (const char* e = getenv("VRT_FUSE_RESTIR")) { if (atoi(e) == 0) fuse_restir = false; }
+    const bool can_fuse = (!restir || fuse_restir) && c->cam.camera_is_moving == 0 && c->cam.render_scale == 1.0f;
     // A persistent render launch ends in a tail: the last paths of every wave bounce on at low occupancy (about 0.16 ms
     // of a 1.5 ms launch at 1080p).  Fused launches of the pooled kernel are therefore OVERLAPPED: launch k+1 goes to
     // the next of n_streams render streams and writes the next copy of the colour planes / g-buffer while launch k drains
     // and its temporal pass (main stream, waits for launch k only) runs.  With n_streams + 1 copies launch k+n_streams+1
     // reuses launch k's and waits for temporal pass k, so render launches follow each other without a gap and the temporal
     // passes run beside them (ensure_overlap: how deep).  Results are unchanged; VRT_OVERLAP=0 turns it off.
-    bool may_overlap = c->pooled && can_fuse;
+    bool may_overlap = c->pooled && can_fuse && !restir;
     if (const char* e = getenv("VRT_OVERLAP")) { if (atoi(e) == 0) may_overlap = false; }
     for (int done = 0; done < n_samples;) {
         int g = (can_fuse && n_samples - done > 1) ? (n_samples - done < max_fused ? n_samples - done : max_fused) : 1;
@@ -716,7 +727,6 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         SceneData sc = make_scene_data(c);
         PixelBuffers out;
         f3* rt = c->d_cbuf[c->cidx];       // render target: holds the previous HDR outside the render area
-        f3* hdr = c->d_cbuf[c->cidx ^ 1];
         // specular colour and raw reflection depth: VRT_MAX_FUSED planes each, the LAST plane being the buffer the
         // reference knows (color_buffer_specular, gbuff_depth_reflection); a fused launch ends on it, so whatever
         // later reads stale pixels (moving camera at half render scale) finds the last sample there, as in the reference
@@ -733,7 +743,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             HIP_TRY(hipMemcpyAsync(c->d_gb_depth[c->cur], c->d_gb_depth[c->prev_gb], c->npix * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
         }
         out.gb_position = set ? c->alt_gb_pos[set - 1] : c->d_gb_pos; out.gb_mat = set ? c->alt_gb_mat[set - 1] : c->d_gb_mat;
-        out.reservoir = c->d_res[0];
+        out.reservoir = restir ? c->d_res[0] - (size_t)(g - 1) * c->npix : nullptr;
         hipEvent_t a, b;
         if (record(c, 0, &a, &b) != VRT_OK) return VRT_E_DEVICE;
         HIP_TRY(hipEventRecord(a, rs));
@@ -761,36 +771,46 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_r[set], 0));
             c->last_render_set = set;
         }
-        const f3* cd = out.color_d;
-        const f3* cs = out.color_s;
-        if (restir) {
-            GrisBuffers gb;
-            gb.color_d_in = rt; gb.color_s_in = c->d_color_s; gb.color_d_out = c->d_color_d2; gb.color_s_out = c->d_color_s2;
-            gb.gb_normal = out.gb_normal; gb.gb_depth = out.gb_depth; gb.gb_mat = out.gb_mat;
-            gb.res_in = c->d_res[0]; gb.res_out = c->d_res[1];
-            gb.geo = c->d_gris_geo; gb.src = c->d_gris_src; gb.mats_x = c->d_mats_x;
-            int g0 = c->own0 - 2 < c->buf0 ? c->buf0 : c->own0 - 2, g1 = c->own1 + 2 > c->buf1 ? c->buf1 : c->own1 + 2;
-            if (record(c, 2, &a, &b) != VRT_OK) return VRT_E_DEVICE;
+        // ReSTIR: spatial reuse and accumulation sample by sample over the planes of the launch (one pass with one sample)
+        const int passes = restir ? g : 1;
+        for (int s = 0; s < passes; s++) {
+            const size_t off = (size_t)s * (size_t)out.sample_stride;   // this sample's plane (ReSTIR; stride 0 with one sample)
+            FrameParams fps = fp;
+            fps.frame = fp.frame + (uint32_t)s;
+            const f3* cd = out.color_d;
+            const f3* cs = out.color_s;
+            if (restir) {
+                GrisBuffers gb;
+                gb.color_d_in = out.color_d + off; gb.color_s_in = out.color_s + off; gb.color_d_out = c->d_color_d2; gb.color_s_out = c->d_color_s2;
+                gb.gb_normal = out.gb_normal; gb.gb_depth = out.gb_depth; gb.gb_mat = out.gb_mat;
+                gb.res_in = out.reservoir + off; gb.res_out = c->d_res[1];
+                gb.geo = c->d_gris_geo; gb.src = c->d_gris_src; gb.mats_x = c->d_mats_x;
+                int g0 = c->own0 - 2 < c->buf0 ? c->buf0 : c->own0 - 2, g1 = c->own1 + 2 > c->buf1 ? c->buf1 : c->own1 + 2;
+                if (record(c, 2, &a, &b) != VRT_OK) return VRT_E_DEVICE;
+                HIP_TRY(hipEventRecord(a, c->stream));
+                HIP_TRY(launch_gris(c->stream, c->cfg.grid_res, instr, fps, sc, gb, g0, g1));
+                HIP_TRY(hipEventRecord(b, c->stream));
+                cd = c->d_color_d2;
+                cs = c->d_color_s2;
+            }
+            TemporalBuffers tb;
+            tb.color_d = cd; tb.color_s = cs;
+            tb.gb_normal = out.gb_normal; tb.gb_depth = out.gb_depth; tb.gb_mat = out.gb_mat;
+            tb.gb_refl_raw = out.gb_refl_depth + (restir ? off : 0); tb.gb_refl_filtered = c->d_gb_refl_f;
+            tb.hist_d_in = c->d_hist_d[c->hist_in]; tb.hist_d_out = c->d_hist_d[c->hist_in ^ 1];
+            tb.hist_s_in = c->d_hist_s[c->hist_in]; tb.hist_s_out = c->d_hist_s[c->hist_in ^ 1];
+            // (the "previous" g-buffer of a launch's later samples is the launch's own: a launch per sample would have written it again)
+            const int prev = s == 0 ? c->prev_gb : c->cur;
+            tb.prev_normal = c->d_gb_normal[prev]; tb.prev_depth = c->d_gb_depth[prev];
+            tb.hdr = c->d_cbuf[c->cidx ^ 1];
+            tb.sample_stride = restir ? 0 : out.sample_stride;
+            tb.prev_view = c->prev_view; tb.prev_proj = c->prev_proj;
+            if (record(c, 1, &a, &b) != VRT_OK) return VRT_E_DEVICE;
             HIP_TRY(hipEventRecord(a, c->stream));
-            HIP_TRY(launch_gris(c->stream, c->cfg.grid_res, instr, fp, sc, gb, g0, g1));
+            HIP_TRY(launch_temporal(c->stream, fps, tb, c->own0, c->own1, restir ? 1 : g));
             HIP_TRY(hipEventRecord(b, c->stream));
-            cd = c->d_color_d2;
-            cs = c->d_color_s2;
+            if (s + 1 < passes) { c->hist_in ^= 1; c->cidx ^= 1; }   // (the last pass's swaps are the iteration's, below)
         }
-        TemporalBuffers tb;
-        tb.color_d = cd; tb.color_s = cs;
-        tb.gb_normal = out.gb_normal; tb.gb_depth = out.gb_depth; tb.gb_mat = out.gb_mat;
-        tb.gb_refl_raw = out.gb_refl_depth; tb.gb_refl_filtered = c->d_gb_refl_f;
-        tb.hist_d_in = c->d_hist_d[c->hist_in]; tb.hist_d_out = c->d_hist_d[c->hist_in ^ 1];
-        tb.hist_s_in = c->d_hist_s[c->hist_in]; tb.hist_s_out = c->d_hist_s[c->hist_in ^ 1];
-        tb.prev_normal = c->d_gb_normal[c->prev_gb]; tb.prev_depth = c->d_gb_depth[c->prev_gb];
-        tb.hdr = hdr;
-        tb.sample_stride = out.sample_stride;
-        tb.prev_view = c->prev_view; tb.prev_proj = c->prev_proj;
-        if (record(c, 1, &a, &b) != VRT_OK) return VRT_E_DEVICE;
-        HIP_TRY(hipEventRecord(a, c->stream));
-        HIP_TRY(launch_temporal(c->stream, fp, tb, c->own0, c->own1, g));
-        HIP_TRY(hipEventRecord(b, c->stream));
         // pathtracer.py:1298-1303 copy loop == pointer swaps
         if (overlapped) {
             HIP_TRY(hipEventRecord(c->ev_t[set], c->stream));

@@ -124,7 +124,7 @@ VRT_DEV void restir_finish(const FrameParams& fp, const SceneData& sc, const Pix
     } else {
         r.weight = 1.0f;
     }
-    out.reservoir[local_idx] = reservoir_encode(r);
+    out.reservoir[local_idx + p.sample * out.sample_stride] = reservoir_encode(r);   // (one plane per fused sample, like the colours)
     if (!chose_nee) {
         diffuse = diffuse + ((p.first_lobe == LOBE_DIFFUSE) ? r.z.F : mk3(0.0f));
         specular = specular + ((p.first_lobe == LOBE_SPEC) ? r.z.F : mk3(0.0f));
