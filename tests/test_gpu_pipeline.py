@@ -97,6 +97,41 @@ def test_pipeline_depths_over_many_launches(monkeypatch):
     assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32))
 
 
+def test_restir_samples_fused_in_the_render_launch(monkeypatch):
+    """With ReSTIR on the render launch carries a call's samples (one reservoir plane each) and spatial reuse / accumulation
+    run per sample over the planes: same HDR, g-buffer and histories as one launch per sample (VRT_FUSE_RESTIR=0), also when
+    a pass that renders part of the frame (moving camera) follows and reads the last sample's reservoirs."""
+    from voxel_rt2_amd import _abi, camera
+    mat, rgb, params = scenes.scene_sunlit(0)
+    cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=DEPTH, seed=9, use_restir=True)
+
+    def run():
+        s = NativeSession(_lib.load(), "vrt_", cfg)
+        orc.setup(s, mat, rgb, params)
+        for n in (4, 3):
+            s.accumulate(n)
+        s.end_frame()
+        pos = (0.46, 0.5, 2.0)
+        view, proj = camera.default_matrices(W, H, pos=pos)
+        s.set_camera(host.make_camera(view, proj, pos, jitter_index=2, moving=True, render_scale=0.5, max_accum_frames=50.0))
+        s.accumulate(1)
+        s.end_frame()
+        s.set_camera(host.make_camera(view, proj, pos, jitter_index=3))
+        s.accumulate(4)
+        out = [s.fetch_hdr()] + [s.fetch_buffer(b) for b in (_abi.BUF_GBUF_DEPTH, _abi.BUF_GBUF_NORMAL, _abi.BUF_GBUF_MAT,
+                                                            _abi.BUF_HISTORY_DIFFUSE, _abi.BUF_HISTORY_SPECULAR)]
+        s.close()
+        return out
+
+    monkeypatch.setenv("VRT_FUSE_RESTIR", "0")
+    ref = run()
+    monkeypatch.delenv("VRT_FUSE_RESTIR")
+    got = run()
+    assert np.isfinite(ref[0]).all() and ref[0].mean() > 0.01
+    for a, b in zip(ref, got):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
 def test_reserved_workgroup_slots_change_nothing(reference_frame):
     hdr, _ = render(reserve=8)
     assert np.array_equal(hdr.view(np.uint32), reference_frame.view(np.uint32))
