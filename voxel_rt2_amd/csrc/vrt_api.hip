@@ -773,6 +773,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         }
         // ReSTIR: spatial reuse and accumulation sample by sample over the planes of the launch (one pass with one sample)
         const int passes = restir ? g : 1;
+        int hist = c->hist_in, ci = c->cidx;   // (the context's own copies only move once every launch of the iteration is queued)
         for (int s = 0; s < passes; s++) {
             const size_t off = (size_t)s * (size_t)out.sample_stride;   // this sample's plane (ReSTIR; stride 0 with one sample)
             FrameParams fps = fp;
@@ -797,21 +798,20 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             tb.color_d = cd; tb.color_s = cs;
             tb.gb_normal = out.gb_normal; tb.gb_depth = out.gb_depth; tb.gb_mat = out.gb_mat;
             tb.gb_refl_raw = out.gb_refl_depth + (restir ? off : 0); tb.gb_refl_filtered = c->d_gb_refl_f;
-            tb.hist_d_in = c->d_hist_d[c->hist_in]; tb.hist_d_out = c->d_hist_d[c->hist_in ^ 1];
-            tb.hist_s_in = c->d_hist_s[c->hist_in]; tb.hist_s_out = c->d_hist_s[c->hist_in ^ 1];
+            tb.hist_d_in = c->d_hist_d[hist]; tb.hist_d_out = c->d_hist_d[hist ^ 1];
+            tb.hist_s_in = c->d_hist_s[hist]; tb.hist_s_out = c->d_hist_s[hist ^ 1];
             // (the "previous" g-buffer of a launch's later samples is the launch's own: a launch per sample would have written it again)
             const int prev = s == 0 ? c->prev_gb : c->cur;
             tb.prev_normal = c->d_gb_normal[prev]; tb.prev_depth = c->d_gb_depth[prev];
-            tb.hdr = c->d_cbuf[c->cidx ^ 1];
+            tb.hdr = c->d_cbuf[ci ^ 1];
             tb.sample_stride = restir ? 0 : out.sample_stride;
             tb.prev_view = c->prev_view; tb.prev_proj = c->prev_proj;
             if (record(c, 1, &a, &b) != VRT_OK) return VRT_E_DEVICE;
             HIP_TRY(hipEventRecord(a, c->stream));
             HIP_TRY(launch_temporal(c->stream, fps, tb, c->own0, c->own1, restir ? 1 : g));
             HIP_TRY(hipEventRecord(b, c->stream));
-            if (s + 1 < passes) { c->hist_in ^= 1; c->cidx ^= 1; }   // (the last pass's swaps are the iteration's, below)
+            hist ^= 1; ci ^= 1;   // pathtracer.py:1298-1303 copy loop == pointer swaps, once per accumulation pass
         }
-        // pathtracer.py:1298-1303 copy loop == pointer swaps
         if (overlapped) {
             HIP_TRY(hipEventRecord(c->ev_t[set], c->stream));
             c->ev_t_valid[set] = true;
@@ -820,10 +820,10 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             for (int s = 0; s < c->n_streams + 1; s++) { HIP_TRY(hipEventRecord(c->ev_t[s], c->stream)); c->ev_t_valid[s] = true; }
         }
         c->last_set = set;
-        c->hist_in ^= 1;
+        c->hist_in = hist;
         c->prev_gb = c->cur;
         c->cur = (c->cur + 1) % VRT_GB_ROT;
-        c->cidx ^= 1;
+        c->cidx = ci;
         c->frame += (uint32_t)g;
         c->stats.path_samples += (uint64_t)g * (uint64_t)c->cfg.width * (uint64_t)(c->own1 - c->own0);
         done += g;
