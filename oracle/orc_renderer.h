@@ -106,10 +106,11 @@ struct Renderer {
         if (nt <= 1) { fn(r0, r1, &stats); return; }
         std::vector<std::thread> th;
         std::vector<Stats> st(nt);
-        /* interleaved 4-row strips for load balance */
+        /* interleaved strips for load balance: 4 rows, fewer when there are not 4 rows per thread (a few sky-table columns) */
+        const int strip = rows >= 4 * nt ? 4 : 1;
         for (int t = 0; t < nt; t++)
             th.emplace_back([&, t]() {
-                for (int r = r0 + 4 * t; r < r1; r += 4 * nt) fn(r, (r + 4 < r1) ? r + 4 : r1, &st[t]);
+                for (int r = r0 + strip * t; r < r1; r += strip * nt) fn(r, (r + strip < r1) ? r + strip : r1, &st[t]);
             });
         for (auto& x : th) x.join();
         for (auto& s : st) {

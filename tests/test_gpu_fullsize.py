@@ -1,5 +1,6 @@
 """BASELINE configs 3 and 4 at their real frame sizes on the GPU, against the oracle on a row shard (the oracle renders
 16 rows of a 1080p / 4K frame in seconds; per-pixel random streams make a shard's pixels those of the full frame)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -38,11 +39,31 @@ def test_config4_full_size_shard_matches_oracle():
     assert np.isfinite(full).all() and full[:, -1].mean() > 0.01 and full[-1].mean() > 0.01   # the last column and row were rendered
 
 
+def _oracle_sky_columns(o, u0, u1, R):
+    """Columns [u0, u1) of both sky tables as the oracle computes them at table size R: Scene.finish()'s 32 cloud passes and
+    the atmosphere pass (scene.py:243-253) restricted to those columns.  A texel of either pass depends on no other texel
+    (atmos.py:140-189), and the random stream of a texel is keyed by (pass, u * R + v), so the columns are the whole table's."""
+    n = u1 - u0
+    assert R % n == 0 and u0 % n == 0
+    o.prepare()   # tables zeroed, cloud pass counter back to 0
+    for _ in range(32):
+        o.sky_accumulate_clouds_slice(32, u0 // n, R // n)
+    o.sky_compute_slice(u0 // n, R // n)
+    scat, trans = np.empty((n, R, 3), np.float32), np.empty((n, R, 3), np.float32)
+    o.sky_table_io(_abi.BUF_SKY_SCATTERING, u0, u1, scat.ctypes.data, 0)
+    o.sky_table_io(_abi.BUF_SKY_TRANSMITTANCE, u0, u1, trans.ctypes.data, 0)
+    return scat, trans
+
+
 def test_config3_full_size_shard_matches_oracle():
-    """Config 3 as benchmarked -- scene S6, physical sky + clouds with the 3840^2 tables, ReSTIR spatial reuse, 1920x1080,
-    8 bounces -- on a 16-row shard through the horizon (26 halo rows each side for the reuse radius), two accumulate passes.
-    The sky tables are computed on the GPU (6 s; the CPU would need hours) and handed to the oracle; that both sides compute
-    the same tables is tested at small sizes (test_sky_precompute_and_lookup_match_oracle)."""
+    """Config 3 as benchmarked -- scene S6, physical sky + clouds with the 3840^2 tables (atmos.py:66-69), ReSTIR spatial reuse,
+    1920x1080, 8 bounces -- on a 16-row shard through the horizon (26 halo rows each side for the reuse radius), two accumulate
+    passes.  The tables are computed on the GPU the way Scene.finish() does (32 cloud passes over the whole table, then 32
+    slices of 120 columns) and compared with the oracle AT THIS SIZE on 64 whole columns, bit for bit: the first and the last
+    16 columns of the table, the 16 around the first slice boundary (columns 112-127: 119 | 120), and the 16 that hold the
+    sun's azimuth; every column carries all 3840 elevations, horizon rows included.  (The oracle needs ~20 s per column and
+    thread, so the other 3776 columns are its only through the same per-texel code.)  The render comparison then runs on the
+    GPU's tables."""
     W, H, rows, R = 1920, 1080, (560, 576), 3840
     mat, rgb, params = scenes.scene_s6(0)
     cloud = np.load(os.path.join(ROOT, "voxel_rt2_amd", "data", "cloud_texture.npy"))
@@ -57,7 +78,16 @@ def test_config3_full_size_shard_matches_oracle():
     scat, trans = g.fetch_buffer(_abi.BUF_SKY_SCATTERING), g.fetch_buffer(_abi.BUF_SKY_TRANSMITTANCE)
     assert np.isfinite(scat).all() and np.isfinite(trans).all() and scat.max() > 0
     o = orc.Oracle(cfg, threads=16)
-    orc.setup(o, mat, rgb, params, cloud=cloud)   # prepare_data builds the (cheap) LUT and cloud ambient; the slices are what is slow
+    orc.setup(o, mat, rgb, params, cloud=cloud)
+    uv = np.zeros(2, dtype=np.float32)
+    sun = np.asarray(host.normalize3(params["light_direction"]), dtype=np.float32)
+    orc.lib().orc_unit_project_sky(C.c_void_p(o._ctx), orc.fptr(sun), orc.fptr(uv))
+    sun_col = int(np.clip(uv[0] * R, 0, R - 1)) & ~15
+    for u0 in sorted({0, 112, sun_col, R - 16}):
+        os_, ot = _oracle_sky_columns(o, u0, u0 + 16, R)
+        assert os_.max() > 0 and np.isfinite(os_).all()
+        assert np.array_equal(scat[u0:u0 + 16].view(np.uint32), os_.view(np.uint32)), f"scattering table, columns {u0}..{u0 + 15}"
+        assert np.array_equal(trans[u0:u0 + 16].view(np.uint32), ot.view(np.uint32)), f"transmittance table, columns {u0}..{u0 + 15}"
     o.upload_sky(scat, trans)
     for s in (g, o):
         s.accumulate(2)
