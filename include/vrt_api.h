@@ -93,7 +93,11 @@ typedef struct vrt_stats {
                                      where a self-test finds that queue operations are serialised, e.g. under rocprofv3 --pmc);
                                      bits 2..4: render launches the pipeline keeps in flight (2 or 4; 0 while not overlapped);
                                      bits 5..7: a launch takes 1 / this many of the workgroup slots (1 or 2);
-                                     bits 8..31: times the host released that wait (error paths, synchronisation watchdog) */
+                                     bits 8..30: times the host released that wait (error paths, synchronisation watchdog);
+                                     bit 31: the carried schedule is in use (launches hand their unfinished paths on; bits 0..7 then 0) */
+    double flush_ms;              /* carried schedule: launches without new work that finish the carried paths before a */
+    uint32_t flush_launches;      /* synchronisation, a fetch or a change of camera / scene (not counted in render_*) */
+    uint32_t reserved0;
 } vrt_stats;
 
 /* buffers readable through vrt_fetch_buffer (tests and the multi-GPU gather) */
@@ -159,6 +163,25 @@ int vrt_fetch_hdr_device_async(vrt_ctx* ctx, void* device_ptr);
 int vrt_set_stream(vrt_ctx* ctx, void* hip_stream);
 /* Renderer.fetch_image (pathtracer.py:1321-1323, 634-662): LDR rgba f32[H][W][4] */
 int vrt_fetch_ldr(vrt_ctx* ctx, float* out);
+/* The reference presents EVERY frame (scene.py:255-262: accumulate, fetch_image, copy_prev_matrices).  These forms of
+ * vrt_fetch_hdr / vrt_fetch_ldr queue the tonemap and the copy behind the passes queued so far, on a stream of the
+ * library's own, and return: the caller goes on queueing frames and collects the image with vrt_fetch_wait(slot),
+ * slot = 0..3 chosen by the caller, one fetch per slot at a time.  `out` should be page-locked memory (vrt_host_alloc) so
+ * that the copy runs beside the following launches; for a shard only its rows of `out` are written. */
+int vrt_fetch_hdr_async(vrt_ctx* ctx, float* out, int slot);
+int vrt_fetch_ldr_async(vrt_ctx* ctx, float* out, int slot);
+int vrt_fetch_wait(vrt_ctx* ctx, int slot);
+/* page-locked host memory for the asynchronous fetches (hipHostMalloc / hipHostFree) */
+int vrt_host_alloc(vrt_ctx* ctx, uint64_t bytes, void** out);
+int vrt_host_free(vrt_ctx* ctx, void* ptr);
+/* Multi-GPU hand-over without a copy (the RCCL gather of the row tiles): the last temporal pass of every
+ * vrt_accumulate call also writes this context's HDR rows (f32[row_end-row_begin][W][3]) to device_ptrs[k % n], k = tiles
+ * written so far; n = 0 ends it.  The pass of a call may be QUEUED up to three calls later (the render launches hand their
+ * unfinished paths on to the next launch instead of ending in a tail; any fetch / sync queues everything):
+ * vrt_hdr_targets_written gives the number of tiles queued on the context's stream so far, so the caller gathers tile k once
+ * the count exceeds k, ordered by an event it records on that stream.  n must exceed 3 + the gathers kept in flight. */
+int vrt_set_hdr_targets(vrt_ctx* ctx, void* const* device_ptrs, int n);
+int vrt_hdr_targets_written(vrt_ctx* ctx, uint64_t* count);
 int vrt_fetch_buffer(vrt_ctx* ctx, int which, void* out);
 int vrt_sync(vrt_ctx* ctx);
 int vrt_get_stats(vrt_ctx* ctx, vrt_stats* out);

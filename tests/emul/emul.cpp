@@ -303,6 +303,7 @@ static int accumulate_g(Emu* c, int n_samples) {
         tb.hdr = hdr;
         tb.sample_stride = 0;
         tb.prev_view = c->prev_view; tb.prev_proj = c->prev_proj;
+        tb.tile = nullptr; tb.tile_row0 = 0;
         for (int v = c->own0; v < c->own1; v++)
             for (int u = 0; u < fp.W; u++) temporal_pixel(fp, tb, u, v, 1);
         c->hist_in ^= 1;

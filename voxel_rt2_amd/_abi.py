@@ -42,6 +42,7 @@ class VrtStats(C.Structure):
         ("render_ms", C.c_double), ("temporal_ms", C.c_double), ("gris_ms", C.c_double),
         ("render_launches", C.c_uint32), ("temporal_launches", C.c_uint32), ("gris_launches", C.c_uint32),
         ("pipeline_flags", C.c_uint32),
+        ("flush_ms", C.c_double), ("flush_launches", C.c_uint32), ("reserved0", C.c_uint32),
     ]
 
     def as_dict(self):
@@ -79,6 +80,13 @@ def declare(lib, prefix):
     sig("set_stream", C.c_int, P, P)
     sig("reserve_cus", C.c_int, P, C.c_int)
     sig("fetch_ldr", C.c_int, P, P)
+    sig("fetch_hdr_async", C.c_int, P, P, C.c_int)
+    sig("fetch_ldr_async", C.c_int, P, P, C.c_int)
+    sig("fetch_wait", C.c_int, P, C.c_int)
+    sig("host_alloc", C.c_int, P, C.c_uint64, C.POINTER(C.c_void_p))
+    sig("host_free", C.c_int, P, P)
+    sig("set_hdr_targets", C.c_int, P, C.POINTER(C.c_void_p), C.c_int)
+    sig("hdr_targets_written", C.c_int, P, C.POINTER(C.c_uint64))
     sig("fetch_buffer", C.c_int, P, C.c_int, P)
     sig("sync", C.c_int, P)
     sig("get_stats", C.c_int, P, C.POINTER(VrtStats))

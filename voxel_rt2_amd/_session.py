@@ -43,6 +43,9 @@ class NativeSession:
 
     def close(self):
         if self._ctx:
+            for ptr, _ in getattr(self, "_pinned", []):
+                getattr(self._lib, self._p + "host_free")(C.c_void_p(self._ctx), C.c_void_p(ptr))
+            self._pinned = []
             getattr(self._lib, self._p + "destroy")(C.c_void_p(self._ctx))
             self._ctx = None
 
@@ -133,6 +136,39 @@ class NativeSession:
         out = np.empty((self.H, self.W, 4), dtype=np.float32)
         self._call("fetch_ldr", out.ctypes.data_as(C.c_void_p))
         return out
+
+    # -- presenting every frame (the reference's accumulate / fetch_image / copy_prev_matrices loop, scene.py:255-262) ---
+    def host_alloc(self, shape, dtype=np.float32):
+        """Page-locked host array (vrt_host_alloc): the target of the asynchronous fetches.  Freed with the session."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = C.c_void_p()
+        self._call("host_alloc", C.c_uint64(n), C.byref(ptr))
+        buf = (C.c_char * n).from_address(ptr.value)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append((ptr.value, arr))
+        return arr
+
+    def fetch_hdr_async(self, out, slot=0):
+        assert out.dtype == np.float32 and out.shape == (self.H, self.W, 3) and out.flags.c_contiguous
+        self._call("fetch_hdr_async", out.ctypes.data_as(C.c_void_p), int(slot))
+
+    def fetch_ldr_async(self, out, slot=0):
+        assert out.dtype == np.float32 and out.shape == (self.H, self.W, 4) and out.flags.c_contiguous
+        self._call("fetch_ldr_async", out.ctypes.data_as(C.c_void_p), int(slot))
+
+    def fetch_wait(self, slot=0):
+        self._call("fetch_wait", int(slot))
+
+    # -- multi-GPU hand-over: the temporal pass writes the rank's HDR tile itself (vrt_set_hdr_targets) ---------------
+    def set_hdr_targets(self, device_ptrs):
+        arr = (C.c_void_p * len(device_ptrs))(*[int(p) for p in device_ptrs])
+        self._call("set_hdr_targets", arr, len(device_ptrs))
+
+    def hdr_targets_written(self):
+        n = C.c_uint64(0)
+        self._call("hdr_targets_written", C.byref(n))
+        return int(n.value)
 
     _BUF = {
         _abi.BUF_GBUF_DEPTH: (np.float32, 1), _abi.BUF_GBUF_NORMAL: (np.uint16, 2), _abi.BUF_GBUF_POSITION: (np.float32, 3),

@@ -37,7 +37,13 @@ struct TemporalBuffers {
     f3* hdr;                      // color_buffer after accumulate(); becomes the next pass's render target
     int sample_stride;            // elements between the planes of consecutive fused samples (colours, raw reflection depth)
     mat4 prev_view, prev_proj;    // prev_view_mat / prev_proj_mat (pathtracer.py:103-104, 283-287)
+    f3* tile;                     // or null: the caller's copy of the HDR rows [tile_row0, ...) (vrt_set_hdr_targets: the tile a
+    int tile_row0;                // multi-GPU rank hands to the gather), written with the frame instead of copied afterwards
 };
+VRT_DEV void store_hdr(const FrameParams& fp, const TemporalBuffers& tb, int idx, int u, int v, f3 c) {
+    tb.hdr[idx] = c;
+    if (tb.tile) tb.tile[(v - tb.tile_row0) * fp.W + u] = c;
+}
 
 VRT_DEV f3 scrub(f3 c) {  // pathtracer.py:1069-1075
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -144,7 +150,7 @@ VRT_DEV void temporal_pixel(const FrameParams& fp, const TemporalBuffers& tb, in
     if (outside_render_area(fp, (float)u, (float)v)) {
         // not rendered at this render_scale: the reference leaves color_buffer (= the last HDR value) untouched.
         // The render target and the HDR target swap roles every pass, so carry the value across.
-        tb.hdr[idx] = tb.color_d[idx];
+        store_hdr(fp, tb, idx, u, v, tb.color_d[idx]);
         tb.hist_d_out[idx] = tb.hist_d_in[idx];
         tb.hist_s_out[idx] = tb.hist_s_in[idx];
         return;
@@ -170,7 +176,7 @@ VRT_DEV void temporal_pixel(const FrameParams& fp, const TemporalBuffers& tb, in
     const float nl_depth = tb.gb_depth[idx];
     const f3 x1 = xform(fp.view_inv, screen_to_view(tc, nl_depth, fp.proj_inv), 1.0f);
     if (near_zero3(x1)) {  // both filters `continue`: colour stays the scrubbed diffuse sample, histories persist
-        tb.hdr[idx] = scrub(tb.color_d[last + idx]);
+        store_hdr(fp, tb, idx, u, v, scrub(tb.color_d[last + idx]));
         tb.hist_d_out[idx] = tb.hist_d_in[idx];
         tb.hist_s_out[idx] = tb.hist_s_in[idx];
         return;
@@ -202,7 +208,7 @@ VRT_DEV void temporal_pixel(const FrameParams& fp, const TemporalBuffers& tb, in
     tb.hist_s_out[idx] = hs;
     f3 col = mk3(hd.x, hd.y, hd.z);
     if (fp.camera_is_moving == 1) col = col * unpack_albedo(tb.gb_mat[idx]);  // re-modulate albedo (:1227-1228)
-    tb.hdr[idx] = col + mk3(hs.x, hs.y, hs.z);
+    store_hdr(fp, tb, idx, u, v, col + mk3(hs.x, hs.y, hs.z));
 }
 
 // Renderer._render_to_image (pathtracer.py:634-662) with uchimura (math_utils.py:163-186)
