@@ -10,14 +10,16 @@ before the timed region.
 
 N > 1 is launched by the driver through torch.distributed.run, one rank per GPU: the frame is
 split into N contiguous row tiles (strong scaling: the frame is fixed), every rank renders its
-tile with no data-path communication, and the HDR tiles are gathered to rank 0 over RCCL at the
-end of every step (inside the timed region).
+tile with no data-path communication, and every step's HDR tiles are gathered to rank 0 over RCCL
+(inside the timed region).
 
 Rank 0 prints ONE JSON line: the headline throughput, the roofline of its dominant kernel
-(k_render_pool), the CPU-oracle baseline timed on this box's host cores and -- on one GPU -- a
-`secondary` list with the other BASELINE configs in their one-GPU form (config 3: sky + clouds +
-ReSTIR at 1080p; config 4: dense 128^3 at 3840x2160; config 5: dense 256^3 at 3840x2160), each
-with its own dominant kernel, duration, algorithmic bytes and roofline fraction.
+(k_render_pool), the CPU-oracle baseline timed on this box's host cores and a `secondary` list:
+on one GPU the other BASELINE configs in their one-GPU form (config 3: sky + clouds + ReSTIR at
+1080p; config 4: dense 128^3 at 3840x2160; config 5: dense 256^3 at 3840x2160), each with its own
+dominant kernel, duration, algorithmic bytes and roofline fraction, plus the reference's own loop
+shape (one sample per call, `scene_api_default`); on N GPUs configs 4 and 5 as BASELINE.json
+defines them -- rows split N ways, the gather inside the timed region.
 """
 import argparse
 import ctypes as C
@@ -216,14 +218,201 @@ def run_secondary(lib, case, counters):
     else:
         kernel, kms, units = "k_render_pool", ms["render"], per_launch
         b_ref, b_timed = render_bytes(work["reference"]), render_bytes(work["timed"])
-        note = "unit = one path-sample; launches overlap, so the kernel duration is a launch's span and the step period is ms_per_step"
+        note = "unit = one path-sample; one launch per step (launches follow one another and hand their unfinished paths on)"
     period = dt / steps * 1e3 / (spp if case.get("restir") else max(st["render_launches"], 1) / steps)
-    return {"config": case["config"], "name": case["name"], "workload": case["workload"], "metric": "Mpath-samples/sec", "value": round(px * spp * steps / dt / 1e6, 2),
+    carried = bool(st.get("pipeline_flags", 0) >> 31)
+    value = px * spp * steps / dt / 1e6
+    return {"config": case["config"], "name": case["name"], "workload": case["workload"], "metric": "Mpath-samples/sec", "value": round(value, 2),
             "unit": "Mpath-samples/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "finite": hdr_ok,
+            "rays_per_s": rays_block(value, work),
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in ms.items()},
             "work_per_path_sample": {k: {a: round(b, 3) for a, b in v.items()} for k, v in work.items()},
             "roofline": roofline_block(kernel, kms, units, b_ref, b_timed, counters.get(case["name"], {}), note,
-                                       None if case.get("restir") else period)}
+                                       None if (case.get("restir") or carried) else period)}
+
+
+class ShardedRun:
+    """One workload on `world` ranks: contiguous row tiles (optionally balanced by measured cost), per step one vrt_accumulate
+    and the RCCL gather of the HDR tiles to rank 0.  The tile is written by the temporal pass itself into a ring of device
+    tensors (vrt_set_hdr_targets); on the library's carried schedule the pass of step k is queued up to three steps later, so
+    the gather of step k is issued when vrt_hdr_targets_written says its tile is queued -- every step's tile is gathered, and
+    finish() (inside the timed region) queues and gathers the last ones.  world == 1: no tiles, no gather."""
+
+    N_TILES = 8   # > the three steps a pass may lag + the gathers in flight
+
+    def __init__(self, lib, dist, torch, *, scene, W, H, depth, spp, grid=128, rank=0, world=1, local_rank=0, rehearse=False, balance=False):
+        from voxel_rt2_amd import host, parallel
+        from voxel_rt2_amd._session import NativeSession
+        self.lib, self.dist, self.torch, self.parallel = lib, dist, torch, parallel
+        self.W, self.H, self.spp, self.rank, self.world, self.rehearse = W, H, spp, rank, world, rehearse
+        self.mat, self.rgb, self.params = scene
+        self.stream = torch.cuda.Stream()   # the context's stream: temporal passes (the render launches go to the library's own)
+        self.coll_dev = "cpu" if rehearse else "cuda"
+
+        def make_session(rows):
+            cfg = host.make_config(W, H, voxel_edges=self.params["voxel_edges"], exposure=self.params["exposure"], max_depth=depth,
+                                   seed=SEED, device=local_rank, rows=rows if world > 1 else None, grid_res=grid)
+            s = NativeSession(lib, "vrt_", cfg)
+            s.set_stream(self.stream.cuda_stream)
+            parallel.configure_session(s, world)   # N > 1: leave workgroup slots free for RCCL's kernels
+            setup_session(s, self.mat, self.rgb, self.params)
+            return s
+
+        self.make_full_session = lambda: make_session(None)
+        # Row tiles: start from an equal split, then (untimed) let every rank measure its tile's device time and move the
+        # tile boundaries so that all ranks carry the same cost -- the sky rows of S1 cost a fraction of the floor rows.
+        self.bounds = split_rows(H, world)
+        self.sess = make_session(self.bounds[rank])
+        if balance and world > 1:
+            user_overlap = os.environ.get("VRT_OVERLAP")
+            os.environ["VRT_OVERLAP"] = "0"  # isolated launches while measuring
+            for _ in range(2):
+                self.sess.accumulate(spp)
+                lib.vrt_reset_stats(C.c_void_p(self.sess._ctx))
+                self.sess.accumulate(spp)
+                st0 = self.sess.stats()
+                mine = torch.tensor([st0["render_ms"] + st0["temporal_ms"]], dtype=torch.float64, device=self.coll_dev)
+                allc = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allc, mine)
+                self.bounds = parallel.rebalance_rows(self.bounds, [float(t.item()) for t in allc], H)
+                self.sess.close()
+                self.sess = make_session(self.bounds[rank])
+            if user_overlap is None:
+                os.environ.pop("VRT_OVERLAP", None)
+            else:
+                os.environ["VRT_OVERLAP"] = user_overlap
+        self.steps_done = 0
+        self.tiles_gathered = 0
+        if world > 1:
+            max_rows = max(b - a for a, b in self.bounds)
+            # every rank's tile is padded to the tallest: the library writes the rank's own rows at the top of its tile
+            self.tiles = [torch.zeros((max_rows, W, 3), dtype=torch.float32, device="cuda") for _ in range(self.N_TILES)]
+            self.gathered = [torch.zeros_like(self.tiles[0]) for _ in range(world)] if rank == 0 else None
+            self.host_gathered = [torch.zeros_like(self.tiles[0], device="cpu") for _ in range(world)] if (rehearse and rank == 0) else None
+            self.gather_stream = torch.cuda.Stream()
+            self.tile_free = [None] * self.N_TILES   # recorded on gather_stream when the gather that read tiles[j] is done
+            self.sess.set_hdr_targets([t.data_ptr() for t in self.tiles])
+
+    def _gather_ready_tiles(self):
+        torch, dist = self.torch, self.dist
+        n = self.sess.hdr_targets_written()
+        if n == self.tiles_gathered:
+            return
+        ready = self.stream.record_event()   # behind the passes that write the tiles
+        with torch.cuda.stream(self.gather_stream):
+            self.gather_stream.wait_event(ready)
+            while self.tiles_gathered < n:
+                j = self.tiles_gathered % self.N_TILES
+                if self.rehearse:
+                    dist.gather(self.tiles[j].cpu(), self.host_gathered, dst=0)
+                    if self.rank == 0:
+                        for g, h in zip(self.gathered, self.host_gathered):
+                            g.copy_(h)
+                else:
+                    dist.gather(self.tiles[j], self.gathered, dst=0)
+                self.tile_free[j] = self.gather_stream.record_event()
+                self.tiles_gathered += 1
+
+    def step(self):
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            if self.world > 1:
+                j = self.steps_done % self.N_TILES   # the tile this step's pass will write, whenever it is queued
+                if self.tile_free[j] is not None:
+                    self.stream.wait_event(self.tile_free[j])
+            self.sess.accumulate(self.spp)
+        self.steps_done += 1
+        if self.world > 1:
+            self._gather_ready_tiles()
+
+    def finish(self):
+        """Everything queued so far completes: the last passes, their tiles' gathers, all ranks."""
+        torch = self.torch
+        if self.world > 1:
+            self.sess.sync()               # the carried paths end, the last passes are queued (and awaited)
+            self._gather_ready_tiles()
+            assert self.tiles_gathered == self.steps_done
+            self.gather_stream.synchronize()
+        else:
+            self.sess.sync()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, steps, warmup):
+        for _ in range(4):   # set-up, not warm-up: the library allocates its pipeline's buffers on the first launches
+            self.step()
+        self.finish()
+        for _ in range(warmup):
+            self.step()
+        self.finish()
+        self.lib.vrt_reset_stats(C.c_void_p(self.sess._ctx))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.finish()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.coll_dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, self.sess.stats()
+
+    def check_against_unsharded(self, label):
+        """Rehearsal only (rank 0): the frame assembled from the LAST gathered tiles equals an unsharded render of the same steps."""
+        full = np.concatenate([self.gathered[r][: self.bounds[r][1] - self.bounds[r][0]].cpu().numpy() for r in range(self.world)], axis=0)
+        one = self.make_full_session()
+        for _ in range(self.steps_done):
+            one.accumulate(self.spp)
+        ref = one.fetch_hdr()
+        one.close()
+        same = bool(np.array_equal(full.view(np.uint32), ref.view(np.uint32)))
+        print(f"[rehearsal] {label}: gathered frame == unsharded frame: {same}", file=sys.stderr, flush=True)
+        if not same:
+            raise SystemExit(f"rehearsal ({label}): gathered frame differs from the unsharded render")
+
+    def close(self):
+        self.sess.close()
+
+
+def rays_block(value_mpaths, work):
+    """Rays per second beside path-samples per second: S1's paths average 1.8 rays (most end on the black sky after one bounce),
+    the dense scenes' 6.1."""
+    return {"unit": "Grays/s", "reference_algorithm": round(value_mpaths * work["reference"]["rays"] / 1e3, 3),
+            "timed_schedule": round(value_mpaths * work["timed"]["rays"] / 1e3, 3),
+            "note": "path-samples/s x rays per path-sample (closest-hit + shadow rays the reference would trace / the timed schedule walks)"}
+
+
+def scene_api_default(lib):
+    """The reference's own loop shape on one GPU (scene.py:177, 233-262: samples_per_frame = 1; every frame set_proj_mat draws a
+    new jitter, accumulate() once, copy_prev_matrices()) -- what `Scene.finish()` and example1..10.py run by default."""
+    from voxel_rt2_amd import host, scenes
+    from voxel_rt2_amd._session import NativeSession
+    mat, rgb, params = scenes.scene_s1(0)
+    cfg = host.make_config(WIDTH, HEIGHT, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=MAX_DEPTH, seed=SEED)
+    s = NativeSession(lib, "vrt_", cfg)
+    setup_session(s, mat, rgb, params)
+    cams = [host.default_camera(WIDTH, HEIGHT, jitter_index=k + 1) for k in range(16)]
+
+    def frames(n, k0):
+        for k in range(n):
+            s.set_camera(cams[(k0 + k) % 16])
+            s.accumulate(1)
+            s.end_frame()
+    frames(40, 0)
+    s.sync()
+    n = 240
+    t0 = time.perf_counter()
+    frames(n, 40)
+    s.sync()
+    dt = time.perf_counter() - t0
+    ok = bool(np.isfinite(s.fetch_hdr()).all())
+    s.close()
+    return {"config": "2, as the Scene API drives it", "name": "scene_api_default", "metric": "Mpath-samples/sec", "unit": "Mpath-samples/s",
+            "workload": "scene S1, 1920x1080, 8 bounces, ONE sample per vrt_accumulate call, a new TAA jitter (vrt_set_camera) and "
+                        "vrt_end_frame per frame: the reference's samples_per_frame = 1 loop (scene.py:177, 233-262)",
+            "value": round(WIDTH * HEIGHT * n / dt / 1e6, 2), "steps": n, "ms_per_step": round(dt / n * 1e3, 4), "finite": ok}
 
 
 def main():
@@ -235,8 +424,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
-    from voxel_rt2_amd import host, scenes, _lib, parallel
-    from voxel_rt2_amd._session import NativeSession
+    from voxel_rt2_amd import scenes, _lib, parallel
     lib = _lib.load()   # before torch touches the device: the library picks the HIP runtime torch ships (and the queue count)
     import torch
     import torch.distributed as dist
@@ -263,125 +451,18 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    coll_dev = "cpu" if rehearse else "cuda"
+    common = dict(rank=rank, world=world, local_rank=local_rank, rehearse=rehearse)
 
-    mat, rgb, params = scenes.scene_s1(0)
-    stream = torch.cuda.Stream()  # the context's stream: temporal passes and the tile copy (render launches go to the library's own streams)
-
-    def make_session(rows):
-        cfg = host.make_config(WIDTH, HEIGHT, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=MAX_DEPTH,
-                               seed=SEED, device=local_rank, rows=rows if world > 1 else None)
-        s = NativeSession(lib, "vrt_", cfg)
-        s.set_stream(stream.cuda_stream)
-        parallel.configure_session(s, world)   # N > 1: leave workgroup slots free for RCCL's kernels
-        setup_session(s, mat, rgb, params)
-        return s
-
-    # Row tiles: start from an equal split, then (untimed) let every rank measure its tile's device time and move the
-    # tile boundaries so that all ranks carry the same cost -- the sky rows of this scene cost a fraction of the floor rows.
-    bounds = split_rows(HEIGHT, world)
-    sess = make_session(bounds[rank])
-    user_overlap = os.environ.get("VRT_OVERLAP")
-    os.environ["VRT_OVERLAP"] = "0"  # isolated launches while measuring: an overlapped launch's span includes its neighbours
-    for _ in range(2 if world > 1 else 0):
-        sess.accumulate(SPP_PER_STEP)
-        lib.vrt_reset_stats(C.c_void_p(sess._ctx))
-        sess.accumulate(SPP_PER_STEP)
-        st0 = sess.stats()
-        mine = torch.tensor([st0["render_ms"] + st0["temporal_ms"]], dtype=torch.float64, device=coll_dev)
-        allc = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allc, mine)
-        bounds = parallel.rebalance_rows(bounds, [float(t.item()) for t in allc], HEIGHT)
-        sess.close()
-        sess = make_session(bounds[rank])
-    if user_overlap is None:
-        os.environ.pop("VRT_OVERLAP", None)
-    else:
-        os.environ["VRT_OVERLAP"] = user_overlap
-    rows = bounds[rank]
-
-    # gather plumbing: equal-sized tiles (padded to the tallest tile), torch owns the staging tensors.  The gather runs on
-    # its own stream behind an event, from one of six staging tiles, so that the next step's temporal pass (same stream as
-    # the tile copy) does not queue behind a collective that waits for the slowest rank.
-    max_rows = max(b - a for a, b in bounds)
-    n_tiles = 6   # deeper than the library's launch pipeline (four launches in flight on a shard this size)
-    tiles = [torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device="cuda") for _ in range(n_tiles)]
-    gathered = [torch.zeros_like(tiles[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
-    host_gathered = [torch.zeros_like(tiles[0], device="cpu") for _ in range(world)] if (rehearse and gathered is not None) else None
-    gather_stream = torch.cuda.Stream() if world > 1 else None
-    tile_free = [None] * n_tiles   # recorded on gather_stream when the gather that read tiles[j] is done
-    step_no = [0]
-
-    def step():
-        j = step_no[0] % n_tiles
-        step_no[0] += 1
-        with torch.cuda.stream(stream):
-            sess.accumulate(SPP_PER_STEP)
-            if world > 1:
-                if tile_free[j] is not None:
-                    stream.wait_event(tile_free[j])
-                sess.fetch_hdr_device_async(tiles[j].data_ptr())  # D2D, queued behind the kernels
-                ready = stream.record_event()
-        if world > 1:
-            with torch.cuda.stream(gather_stream):
-                gather_stream.wait_event(ready)
-                if rehearse:
-                    dist.gather(tiles[j].cpu(), host_gathered, dst=0)
-                    if rank == 0:
-                        for g, h in zip(gathered, host_gathered):
-                            g.copy_(h)
-                else:
-                    dist.gather(tiles[j], gathered, dst=0)
-                tile_free[j] = gather_stream.record_event()
-
-    def fence():
-        stream.synchronize()
-        if gather_stream is not None:
-            gather_stream.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # setup, not warm-up: the library allocates the buffers of its overlapped pipeline (second and third buffer set, the
-    # camera-ray tables of both render streams) on the first launches that use them; keep that out of a short --warmup
-    for _ in range(4):
-        step()
-    fence()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    lib.vrt_reset_stats(C.c_void_p(sess._ctx))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    st = sess.stats()
-
+    scene = scenes.scene_s1(0)
+    mat, rgb, params = scene
+    run = ShardedRun(lib, dist, torch, scene=scene, W=WIDTH, H=HEIGHT, depth=MAX_DEPTH, spp=SPP_PER_STEP, balance=True, **common)
+    elapsed, st = run.timed(args.steps, args.warmup)
     if rehearse and world > 1 and rank == 0:
-        # rehearsal only: the frame assembled from the gathered tiles equals an unsharded render of the same passes
-        full = np.concatenate([gathered[r][: bounds[r][1] - bounds[r][0]].cpu().numpy() for r in range(world)], axis=0)
-        cfg1 = host.make_config(WIDTH, HEIGHT, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=MAX_DEPTH,
-                                seed=SEED, device=local_rank)
-        one = NativeSession(lib, "vrt_", cfg1)
-        setup_session(one, mat, rgb, params)
-        for _ in range(step_no[0]):   # every step() so far: setup, warm-up and timed
-            one.accumulate(SPP_PER_STEP)
-        ref = one.fetch_hdr()
-        one.close()
-        same = np.array_equal(full.view(np.uint32), ref.view(np.uint32))
-        print(f"[rehearsal] gathered frame == unsharded frame: {same}", file=sys.stderr, flush=True)
-        if not same:
-            raise SystemExit("rehearsal: gathered frame differs from the unsharded render")
-
+        run.check_against_unsharded("config 2")
+    bounds = run.bounds
     # what a path-sample of this rank's tile does: untimed instrumented launches
-    work = count_work(lib, sess, SPP_PER_STEP)
-    sess.sync()
+    work = count_work(lib, run.sess, SPP_PER_STEP)
+    run.sess.sync()
 
     if rank == 0:
         total_samples = WIDTH * HEIGHT * SPP_PER_STEP * args.steps
@@ -392,11 +473,14 @@ def main():
         counters, counters_note = measured_counters(lib) if world == 1 else ({}, None)
         render_kernel = "k_render" if os.environ.get("VRT_RENDER") == "fused" else "k_render_pool"
         flags = st.get("pipeline_flags", 0)
+        carried = bool(flags >> 31)
         note = ("HBM is the bound the tier names; the 128^3 working set (8.3 MB) is cache resident and the kernel is bound by vector-instruction "
                 "issue under divergence at 2 waves per SIMD (DESIGN.md 7); `achieved` counts the bytes of the schedule that is timed (fused "
                 "samples share their camera rays: queries counted once), `reference_algorithm` the bytes the reference would move for the same "
-                "paths. Launches overlap: `achieved` / `frac` use a launch's span (what the kernel trace shows), `all_launches_in_flight` the "
-                "period between launches (the chip's rate)")
+                "paths. " + ("Launches follow one another on one stream and hand their unfinished paths on (carried schedule): a launch's "
+                             "duration is the period between launches" if carried else
+                             "Launches overlap: `achieved` / `frac` use a launch's span (what the kernel trace shows), `all_launches_in_flight` "
+                             "the period between launches (the chip's rate)"))
         if counters_note:
             note += "; " + counters_note
         out = {
@@ -406,27 +490,59 @@ def main():
             "config": {"workload": "example1-style scene S1 (scenes.scene_s1), 128^3 grid, 1920x1080, 4 spp/step, 8 bounces, "
                                    "static camera, ReSTIR off", "width": WIDTH, "height": HEIGHT, "spp_per_step": SPP_PER_STEP,
                        "max_depth": MAX_DEPTH, "seed": SEED, "build_id": lib.vrt_build_id().decode(),
-                       "launch_pipeline": {"overlapped": bool(flags & 1), "dispatch_gate": bool(flags & 2), "gate_host_releases": int(flags >> 8),
-                                           "launches_in_flight": int((flags >> 2) & 7), "workgroup_slots_per_launch": f"1/{max(int((flags >> 5) & 7), 1)}"},
-                       "sharding": (f"{world} contiguous row tiles, boundaries balanced by measured tile cost, RCCL gather per step, "
-                                    f"{parallel.reserved_cus(world)} CUs' worth of workgroup slots left free for the collective; "
+                       "launch_pipeline": ({"schedule": "carried", "paths_carried_for_launches": 3, "flush_launches_in_timed_region": int(st.get("flush_launches", 0))}
+                                           if carried else
+                                           {"schedule": "overlapped" if flags & 1 else "plain", "dispatch_gate": bool(flags & 2), "gate_host_releases": int((flags >> 8) & 0x7fffff),
+                                            "launches_in_flight": int((flags >> 2) & 7), "workgroup_slots_per_launch": f"1/{max(int((flags >> 5) & 7), 1)}"}),
+                       "sharding": (f"{world} contiguous row tiles, boundaries balanced by measured tile cost, HDR tile written by the temporal pass into a ring "
+                                    f"of {ShardedRun.N_TILES} device tiles, RCCL gather of every step's tile (issued when its pass is queued, all inside the "
+                                    f"timed region), {parallel.reserved_cus(world)} CUs' worth of workgroup slots left free for the collective; "
                                     f"tile rows {[b - a for a, b in bounds]}") if world > 1 else "none"},
             "roofline": roofline_block(render_kernel, avg_ms, samples_per_launch, render_bytes(work["reference"]), render_bytes(work["timed"]),
-                                       counters.get("config2_s1_1080p", {}), note, elapsed / launches * 1e3),
+                                       counters.get("config2_s1_1080p", {}), note, None if carried else elapsed / launches * 1e3),
             "work_per_path_sample": {k: {a: round(b, 3) for a, b in v.items()} for k, v in work.items()},
-            "kernel_ms_per_launch": {"render": round(avg_ms, 4), "temporal": round(st["temporal_ms"] / max(st["temporal_launches"], 1), 4)},
+            "rays_per_s": rays_block(value, work),
+            "kernel_ms_per_launch": {"render": round(avg_ms, 4), "temporal": round(st["temporal_ms"] / max(st["temporal_launches"], 1), 4),
+                                     "flush": round(st.get("flush_ms", 0.0) / max(st.get("flush_launches", 0), 1), 4)},
         }
-    sess.close()
-    if rank == 0:
-        out["secondary"] = None
-        if world == 1 and not args.no_secondary:
-            sec = []
+    run.close()
+
+    sec = None
+    if not args.no_secondary:
+        sec = []
+        if world == 1:
             for case in SECONDARY:
                 try:
                     sec.append(run_secondary(lib, case, counters))
                 except Exception as e:  # a secondary leg must not take the headline down
                     sec.append({"config": case["config"], "name": case["name"], "error": f"{type(e).__name__}: {e}"})
-            out["secondary"] = sec
+            try:
+                sec.append(scene_api_default(lib))
+            except Exception as e:
+                sec.append({"name": "scene_api_default", "error": f"{type(e).__name__}: {e}"})
+        else:
+            # the configs BASELINE.json defines ON N GPUs: rows split N ways, the gather inside the timed region
+            for case in SECONDARY:
+                if case.get("restir"):
+                    continue
+                sc_ = scenes.SCENES[case["scene"]](12345)
+                sc_ = (sc_[0], sc_[1], dict(sc_[2], use_physical_sky=0, use_clouds=0))
+                r2 = ShardedRun(lib, dist, torch, scene=sc_, W=case["W"], H=case["H"], depth=case["depth"], spp=case["spp"], grid=case.get("grid", 128), **common)
+                steps = 2 if rehearse else case["steps"]
+                el, st2 = r2.timed(steps, 1)
+                if rehearse and rank == 0:
+                    r2.check_against_unsharded(case["name"])
+                if rank == 0:
+                    px = case["W"] * case["H"]
+                    sec.append({"config": case["config"].replace(" (one GPU's form)", f" on {world} GPUs"), "name": case["name"] + f"_{world}gpu",
+                                "workload": case["workload"].replace("the whole frame on one GPU", f"rows split over {world} GPUs, RCCL gather of the HDR tiles every step inside the timed region"),
+                                "metric": "Mpath-samples/sec", "unit": "Mpath-samples/s", "value": round(px * case["spp"] * steps / el / 1e6, 2),
+                                "n_gpus": world, "steps": steps, "ms_per_step": round(el / steps * 1e3, 4),
+                                "kernel_ms_per_launch": {"render": round(st2["render_ms"] / max(st2["render_launches"], 1), 4)},
+                                "tile_rows": [b - a for a, b in r2.bounds]})
+                r2.close()
+    if rank == 0:
+        out["secondary"] = sec
         out["cpu_baseline"] = cpu_baseline(mat, rgb, params) if (not args.no_cpu_baseline and world == 1) else None
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -64,10 +64,14 @@ def source_id():
     return h.hexdigest()[:16]
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    if not force and not is_stale():
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """out: an A/B variant (build_variants/libvrt_<name>.so, loaded through VRT_LIB_PATH) instead of the shipped library."""
+    if out is None and not force and not is_stale():
         return OUT
-    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [f'-DVRT_BUILD_ID="{source_id()}"'] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    out = out or OUT
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    tag = source_id() + ("+" + "".join(extra_flags) if extra_flags else "")
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [f'-DVRT_BUILD_ID="{tag}"'] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -76,8 +80,15 @@ def build(force=False, verbose=False, extra_flags=()):
         raise RuntimeError("hipcc failed building libvrt_hip.so")
     if verbose and r.stderr:
         sys.stderr.write(r.stderr)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    # python -m voxel_rt2_amd.build [--force]                      the shipped library
+    # python -m voxel_rt2_amd.build --variant NAME -DFLAG ...      build_variants/libvrt_NAME.so with extra flags (A/B runs)
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        name, extra = sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-")]
+        print(build(force=True, extra_flags=extra, out=os.path.join(os.path.dirname(HERE), "build_variants", f"libvrt_{name}.so")))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -374,7 +374,7 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
     ok = ok && dalloc(&c->d_mat, nvox) == hipSuccess && dalloc(&c->d_rgb, nvox * 3) == hipSuccess && dalloc(&c->d_grid, nvox) == hipSuccess;
     ok = ok && dalloc(&c->d_l0, nw0) == hipSuccess && dalloc(&c->d_l1, nw1) == hipSuccess && dalloc(&c->d_l2, nw2) == hipSuccess &&
          dalloc(&c->d_l3, 1) == hipSuccess && dalloc(&c->d_cull, 16) == hipSuccess && dalloc(&c->d_l0c, 32768) == hipSuccess && dalloc(&c->d_l0c_base, 513) == hipSuccess;
-    ok = ok && dalloc(&c->d_mats, 128 * 14) == hipSuccess && dalloc(&c->d_counters, 1) == hipSuccess && dalloc(&c->d_work, VRT_WORK_SETS * VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE) == hipSuccess;
+    ok = ok && dalloc(&c->d_mats, 128 * 14) == hipSuccess && dalloc(&c->d_counters, 1) == hipSuccess && dalloc(&c->d_work, VRT_WORK_SETS * (VRT_WORK_HEADS + 1) * VRT_WORK_HEAD_STRIDE) == hipSuccess;   // heads, then a flag line per set (CarryArgs::announce)
     ok = ok && dalloc(&c->d_cbuf[0], n) == hipSuccess && dalloc(&c->d_cbuf[1], n) == hipSuccess && dalloc(&c->d_spec_planes, n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->d_gb_pos, n) == hipSuccess;
     ok = ok && dalloc(&c->d_gb_mat, n) == hipSuccess && dalloc(&c->d_refl_planes, n * VRT_MAX_FUSED) == hipSuccess;
     if (ok) { c->d_color_s = c->d_spec_planes + (size_t)(VRT_MAX_FUSED - 1) * n; c->d_gb_refl = c->d_refl_planes + (size_t)(VRT_MAX_FUSED - 1) * n; }
@@ -712,7 +712,7 @@ static void abort_pipeline(vrt_ctx* c) {
     resolve_events(c);
     // the work heads rotate with the launch number and each launch zeroes the set eight launches ahead: a launch that did not
     // run leaves a used set behind -- nothing is in flight now, so all of them start clean
-    (void)hipMemset(c->d_work, 0, VRT_WORK_SETS * VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE * sizeof(unsigned));
+    (void)hipMemset(c->d_work, 0, VRT_WORK_SETS * (VRT_WORK_HEADS + 1) * VRT_WORK_HEAD_STRIDE * sizeof(unsigned));
     (void)hipStreamSynchronize(nullptr);   // (the fill runs on the NULL stream: see dalloc)
     (void)hipGetLastError();
     for (int s = 0; s < VRT_MAX_SETS; s++) c->ev_t_valid[s] = false;
@@ -803,7 +803,7 @@ static int carry_flush(vrt_ctx* c) {
     const unsigned seq = c->launch_seq++;
     HIP_TRY(launch_render_pool_carry(c->carry_stream, c->cfg.grid_res, c->carry_blocks, c->carry_fp, c->carry_sc, carry_out(c), c->d_work, seq, 1,
                                      c->d_pool_scratch, nullptr, c->carry_cull, c->d_carry_state, (int)c->npix, (int)(c->npix * VRT_MAX_FUSED),
-                                     VRT_CARRY_SETS, slot, true));
+                                     VRT_CARRY_SETS, slot, true, false));
     HIP_TRY(hipEventRecord(b, c->carry_stream));
     HIP_TRY(hipEventRecord(c->ev_cr[slot], c->carry_stream));
     while (!c->carry_pending.empty()) {
@@ -853,7 +853,7 @@ static int accumulate_carry(vrt_ctx* c, int g, bool last_of_call) {
     if (c->test_fail_launch >= 0 && (unsigned)c->test_fail_launch == seq) return fail(VRT_E_DEVICE, "injected launch failure (VRT_TEST_FAIL_LAUNCH)");
     HIP_TRY(launch_render_pool_carry(c->carry_stream, c->cfg.grid_res, c->render_blocks, fp, sc, carry_out(c), c->d_work, seq, g, c->d_pool_scratch,
                                      g > 1 ? c->d_carry_prim : nullptr, cull, c->d_carry_state, (int)c->npix, (int)(c->npix * VRT_MAX_FUSED),
-                                     VRT_CARRY_SETS, set, false));
+                                     VRT_CARRY_SETS, set, false, getenv("VRT_CARRY_FINISH_ALL") != nullptr));   // (A/B: every launch ends its own paths)
     HIP_TRY(hipEventRecord(b, c->carry_stream));
     HIP_TRY(hipEventRecord(c->ev_cr[set], c->carry_stream));
     c->carry_fp = fp; c->carry_sc = sc; c->carry_cull = cull;

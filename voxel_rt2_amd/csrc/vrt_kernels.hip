@@ -326,7 +326,13 @@ struct CarryArgs {
     int cur_set;          // set of THIS launch's paths
     uint32_t cur_tag;     // launch number & 3
     int drain_all;        // 1: nothing may be carried out of this launch (the flush before a synchronisation)
+    unsigned* announce;       // raised by the first wave that finds the launch's work used up, polled by the others: a word on a
+    unsigned* next_announce;  // line of its own (2048 waves reading the line of a work head slow its atomics down fourfold)
 };
+#ifndef VRT_CARRY_POLL
+#define VRT_CARRY_POLL 2   // 0: a wave learns that the work is used up from its own BEGIN only; 1: it looks at `announce` at every census;
+                           // 2: only once its own work range is used up (the ranges end together: that is the end of the launch)
+#endif
 #define VRT_CARRY_WAVE_WORDS (VRT_POOL_WORDS * 64 + PF_COUNT * VRT_POOL_SLOTS)
 
 template <int G, bool RESTIR, bool INSTR, bool BLACK_SUN, bool CULL, bool CARRY = false>
@@ -336,7 +342,7 @@ template <int G, bool RESTIR, bool INSTR, bool BLACK_SUN, bool CULL, bool CARRY 
 #ifndef VRT_POOL_HALF_VGPRS
 #define VRT_POOL_HALF_VGPRS 104
 #endif
-__device__ __forceinline__ void render_pool_body(const FrameParams& fp, const SceneData& sc, const PixelBuffers& out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache, const CarryArgs ca = CarryArgs{nullptr, 0, 0, 1, 0, 0u, 0}) {
+__device__ __forceinline__ void render_pool_body(const FrameParams& fp, const SceneData& sc, const PixelBuffers& out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache, const CarryArgs ca = CarryArgs{nullptr, 0, 0, 1, 0, 0u, 0, nullptr, nullptr}) {
     constexpr int WAVES = PoolGeom<G>::waves;
     constexpr bool BIG = (G == 256);   // which coarse levels are staged how: see LdsPyramid2
     __shared__ ulonglong2 s_l12[BIG ? 1 : 512];
@@ -374,6 +380,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
     if (threadIdx.x < 8) s_cull[threadIdx.x] = sc.cull[threadIdx.x];
     if (blockIdx.x == 0 && threadIdx.x < VRT_WORK_HEADS) next_counter[threadIdx.x * VRT_WORK_HEAD_STRIDE] = 0u;  // the next launch's heads (idle during this launch)
     if (blockIdx.x == 0 && threadIdx.x == 0) next_counter[1] = 0u;  // and its "drain announced" word
+    if constexpr (CARRY) { if (blockIdx.x == 0 && threadIdx.x == 0) *ca.next_announce = 0u; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* const pool = s_pool[wave];
     uint32_t* const state = s_state[wave];
@@ -447,7 +454,9 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
         uint32_t st[VRT_POOL_WORDS];
         int cnt[4] = {0, 0, 0, 0};
         uint32_t announced = 0u;
-        if constexpr (CARRY) { if (!exhausted) announced = __builtin_nontemporal_load(work_counter + 1); }  // another wave found the work used up
+        if constexpr (CARRY && VRT_CARRY_POLL != 0) {  // another wave found the work used up
+            if (!exhausted && (VRT_CARRY_POLL == 1 || heads_left < (int)VRT_WORK_HEADS)) announced = __builtin_nontemporal_load(ca.announce);
+        }
         bool must = false;   // CARRY: a path of mine that may not be carried out of this launch
 #pragma unroll
         for (int k = 0; k < VRT_POOL_WORDS; k++) {
@@ -574,7 +583,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
                         exhausted = true;
                         // the launch starts to drain: tell the stream holding the NEXT launch back until now (vrt_api.hip)
                         // (the first wave to get here does; word 1 of this launch's head line says whether one has)
-                        if constexpr (CARRY) { if (lane == 0) __hip_atomic_store(work_counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        if constexpr (CARRY) { if (lane == 0) __hip_atomic_store(ca.announce, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                         else if (drain_signal && lane == 0 && atomicExch(work_counter + 1, 1u) == 0u)
                             __hip_atomic_fetch_max(drain_signal, drain_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
@@ -900,14 +909,17 @@ size_t pool_carry_bytes(int grid_res, int n_blocks) { return (size_t)n_blocks * 
 // launches the flush: no new work, every carried path runs to its end.
 hipError_t launch_render_pool_carry(hipStream_t st, int grid_res, int n_blocks, const FrameParams& fp, const SceneData& sc, const PixelBuffers& out,
                                     unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold, PrimaryRecord* prim_cache, bool cull,
-                                    uint32_t* carry_state, int gb_stride, int plane_stride, int n_sets, int cur_set, bool flush) {
+                                    uint32_t* carry_state, int gb_stride, int plane_stride, int n_sets, int cur_set, bool flush, bool finish_all) {
     unsigned* work_counter = work_counters + (launch_seq & 15u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     unsigned* next_counter = work_counters + ((launch_seq + 8u) & 15u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     dim3 g(n_blocks), b(64 * pool_waves_per_block(grid_res));
     const bool black_sun = !((fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f);
     CarryArgs ca;
     ca.state = carry_state; ca.gb_stride = gb_stride; ca.plane_stride = plane_stride; ca.n_sets = n_sets; ca.cur_set = cur_set;
-    ca.cur_tag = launch_seq & 3u; ca.drain_all = flush ? 1 : 0;
+    ca.cur_tag = launch_seq & 3u; ca.drain_all = (flush || finish_all) ? 1 : 0;
+    unsigned* const flags = work_counters + 16u * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);   // behind the sixteen sets of heads: a line per set
+    ca.announce = flags + (launch_seq & 15u) * VRT_WORK_HEAD_STRIDE;
+    ca.next_announce = flags + ((launch_seq + 8u) & 15u) * VRT_WORK_HEAD_STRIDE;
     FrameParams fpl = fp;
     if (flush) fpl.row1 = fpl.row0;   // no rows, no items: the kernel sees its work used up from the start
     // (the index arithmetic of carried paths uses fp.row0 and fp.W only, which the flush keeps)
