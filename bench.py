@@ -37,7 +37,7 @@ import numpy as np  # noqa: E402
 
 # More hardware queues than the HIP runtime's default 4 (voxel_rt2_amd/_lib.py explains; it sets the same default when
 # the library is loaded first).  Must be in the environment before the runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 WIDTH, HEIGHT, SPP_PER_STEP, MAX_DEPTH, SEED = 1920, 1080, 4, 8, 0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
@@ -218,9 +218,8 @@ def run_secondary(lib, case, counters):
     else:
         kernel, kms, units = "k_render_pool", ms["render"], per_launch
         b_ref, b_timed = render_bytes(work["reference"]), render_bytes(work["timed"])
-        note = "unit = one path-sample; one launch per step (launches follow one another and hand their unfinished paths on)"
+        note = "unit = one path-sample; launches overlap, so the kernel duration is a launch's span and the step period is ms_per_step"
     period = dt / steps * 1e3 / (spp if case.get("restir") else max(st["render_launches"], 1) / steps)
-    carried = bool(st.get("pipeline_flags", 0) >> 31)
     value = px * spp * steps / dt / 1e6
     return {"config": case["config"], "name": case["name"], "workload": case["workload"], "metric": "Mpath-samples/sec", "value": round(value, 2),
             "unit": "Mpath-samples/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "finite": hdr_ok,
@@ -228,17 +227,18 @@ def run_secondary(lib, case, counters):
             "kernel_ms_per_launch": {k: round(v, 4) for k, v in ms.items()},
             "work_per_path_sample": {k: {a: round(b, 3) for a, b in v.items()} for k, v in work.items()},
             "roofline": roofline_block(kernel, kms, units, b_ref, b_timed, counters.get(case["name"], {}), note,
-                                       None if (case.get("restir") or carried) else period)}
+                                       None if case.get("restir") else period)}
 
 
 class ShardedRun:
     """One workload on `world` ranks: contiguous row tiles (optionally balanced by measured cost), per step one vrt_accumulate
     and the RCCL gather of the HDR tiles to rank 0.  The tile is written by the temporal pass itself into a ring of device
-    tensors (vrt_set_hdr_targets); on the library's carried schedule the pass of step k is queued up to three steps later, so
-    the gather of step k is issued when vrt_hdr_targets_written says its tile is queued -- every step's tile is gathered, and
-    finish() (inside the timed region) queues and gathers the last ones.  world == 1: no tiles, no gather."""
+    tensors (vrt_set_hdr_targets: no device-to-device copy behind the pass); the gather of a step is issued, on a stream of
+    its own behind an event, as soon as vrt_hdr_targets_written says its tile is queued -- so that the next step's temporal
+    pass does not queue behind a collective that waits for the slowest rank.  finish() (inside the timed region) completes
+    every gather on every rank.  world == 1: no tiles, no gather."""
 
-    N_TILES = 8   # > the three steps a pass may lag + the gathers in flight
+    N_TILES = 8   # deeper than the library's launch pipeline (eight launches in flight on a shard of an eighth of 1080p)
 
     def __init__(self, lib, dist, torch, *, scene, W, H, depth, spp, grid=128, rank=0, world=1, local_rank=0, rehearse=False, balance=False):
         from voxel_rt2_amd import host, parallel
@@ -329,7 +329,7 @@ class ShardedRun:
         """Everything queued so far completes: the last passes, their tiles' gathers, all ranks."""
         torch = self.torch
         if self.world > 1:
-            self.sess.sync()               # the carried paths end, the last passes are queued (and awaited)
+            self.sess.sync()
             self._gather_ready_tiles()
             assert self.tiles_gathered == self.steps_done
             self.gather_stream.synchronize()
@@ -473,14 +473,11 @@ def main():
         counters, counters_note = measured_counters(lib) if world == 1 else ({}, None)
         render_kernel = "k_render" if os.environ.get("VRT_RENDER") == "fused" else "k_render_pool"
         flags = st.get("pipeline_flags", 0)
-        carried = bool(flags >> 31)
         note = ("HBM is the bound the tier names; the 128^3 working set (8.3 MB) is cache resident and the kernel is bound by vector-instruction "
                 "issue under divergence at 2 waves per SIMD (DESIGN.md 7); `achieved` counts the bytes of the schedule that is timed (fused "
                 "samples share their camera rays: queries counted once), `reference_algorithm` the bytes the reference would move for the same "
-                "paths. " + ("Launches follow one another on one stream and hand their unfinished paths on (carried schedule): a launch's "
-                             "duration is the period between launches" if carried else
-                             "Launches overlap: `achieved` / `frac` use a launch's span (what the kernel trace shows), `all_launches_in_flight` "
-                             "the period between launches (the chip's rate)"))
+                "paths. Launches overlap: `achieved` / `frac` use a launch's span (what the kernel trace shows), `all_launches_in_flight` "
+                "the period between launches (the chip's rate)")
         if counters_note:
             note += "; " + counters_note
         out = {
@@ -490,20 +487,17 @@ def main():
             "config": {"workload": "example1-style scene S1 (scenes.scene_s1), 128^3 grid, 1920x1080, 4 spp/step, 8 bounces, "
                                    "static camera, ReSTIR off", "width": WIDTH, "height": HEIGHT, "spp_per_step": SPP_PER_STEP,
                        "max_depth": MAX_DEPTH, "seed": SEED, "build_id": lib.vrt_build_id().decode(),
-                       "launch_pipeline": ({"schedule": "carried", "paths_carried_for_launches": 3, "flush_launches_in_timed_region": int(st.get("flush_launches", 0))}
-                                           if carried else
-                                           {"schedule": "overlapped" if flags & 1 else "plain", "dispatch_gate": bool(flags & 2), "gate_host_releases": int((flags >> 8) & 0x7fffff),
-                                            "launches_in_flight": int((flags >> 2) & 7), "workgroup_slots_per_launch": f"1/{max(int((flags >> 5) & 7), 1)}"}),
+                       "launch_pipeline": {"overlapped": bool(flags & 1), "dispatch_gate": bool(flags & 2), "gate_host_releases": int(flags >> 8),
+                                           "launches_in_flight": 2 * int((flags >> 2) & 7), "workgroup_slots_per_launch": f"1/{max(int((flags >> 5) & 7), 1)}"},
                        "sharding": (f"{world} contiguous row tiles, boundaries balanced by measured tile cost, HDR tile written by the temporal pass into a ring "
                                     f"of {ShardedRun.N_TILES} device tiles, RCCL gather of every step's tile (issued when its pass is queued, all inside the "
                                     f"timed region), {parallel.reserved_cus(world)} CUs' worth of workgroup slots left free for the collective; "
                                     f"tile rows {[b - a for a, b in bounds]}") if world > 1 else "none"},
             "roofline": roofline_block(render_kernel, avg_ms, samples_per_launch, render_bytes(work["reference"]), render_bytes(work["timed"]),
-                                       counters.get("config2_s1_1080p", {}), note, None if carried else elapsed / launches * 1e3),
+                                       counters.get("config2_s1_1080p", {}), note, elapsed / launches * 1e3),
             "work_per_path_sample": {k: {a: round(b, 3) for a, b in v.items()} for k, v in work.items()},
             "rays_per_s": rays_block(value, work),
-            "kernel_ms_per_launch": {"render": round(avg_ms, 4), "temporal": round(st["temporal_ms"] / max(st["temporal_launches"], 1), 4),
-                                     "flush": round(st.get("flush_ms", 0.0) / max(st.get("flush_launches", 0), 1), 4)},
+            "kernel_ms_per_launch": {"render": round(avg_ms, 4), "temporal": round(st["temporal_ms"] / max(st["temporal_launches"], 1), 4)},
         }
     run.close()
 

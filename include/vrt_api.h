@@ -91,13 +91,9 @@ typedef struct vrt_stats {
     uint32_t pipeline_flags;      /* bit 0: launches of consecutive vrt_accumulate calls overlap; bit 1: the next launch's dispatch
                                      is held until the running one starts to drain (stream wait on a kernel-raised word; left out
                                      where a self-test finds that queue operations are serialised, e.g. under rocprofv3 --pmc);
-                                     bits 2..4: render launches the pipeline keeps in flight (2 or 4; 0 while not overlapped);
-                                     bits 5..7: a launch takes 1 / this many of the workgroup slots (1 or 2);
-                                     bits 8..30: times the host released that wait (error paths, synchronisation watchdog);
-                                     bit 31: the carried schedule is in use (launches hand their unfinished paths on; bits 0..7 then 0) */
-    double flush_ms;              /* carried schedule: launches without new work that finish the carried paths before a */
-    uint32_t flush_launches;      /* synchronisation, a fetch or a change of camera / scene (not counted in render_*) */
-    uint32_t reserved0;
+                                     bits 2..4: HALF the render launches the pipeline keeps in flight (1, 2, 4 for 2, 4, 8; 0 while not overlapped);
+                                     bits 5..7: a launch takes 1 / this many of the workgroup slots (1, 2 or 4);
+                                     bits 8..31: times the host released that wait (error paths, synchronisation watchdog) */
 } vrt_stats;
 
 /* buffers readable through vrt_fetch_buffer (tests and the multi-GPU gather) */
@@ -176,10 +172,9 @@ int vrt_host_alloc(vrt_ctx* ctx, uint64_t bytes, void** out);
 int vrt_host_free(vrt_ctx* ctx, void* ptr);
 /* Multi-GPU hand-over without a copy (the RCCL gather of the row tiles): the last temporal pass of every
  * vrt_accumulate call also writes this context's HDR rows (f32[row_end-row_begin][W][3]) to device_ptrs[k % n], k = tiles
- * written so far; n = 0 ends it.  The pass of a call may be QUEUED up to three calls later (the render launches hand their
- * unfinished paths on to the next launch instead of ending in a tail; any fetch / sync queues everything):
- * vrt_hdr_targets_written gives the number of tiles queued on the context's stream so far, so the caller gathers tile k once
- * the count exceeds k, ordered by an event it records on that stream.  n must exceed 3 + the gathers kept in flight. */
+ * written so far (vrt_hdr_targets_written); n = 0 ends it.  The pass is queued on the context's stream by the call, so an
+ * event the caller records on that stream afterwards orders the gather behind the tile; n must exceed the gathers the
+ * caller keeps in flight. */
 int vrt_set_hdr_targets(vrt_ctx* ctx, void* const* device_ptrs, int n);
 int vrt_hdr_targets_written(vrt_ctx* ctx, uint64_t* count);
 int vrt_fetch_buffer(vrt_ctx* ctx, int which, void* out);

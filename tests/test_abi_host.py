@@ -20,7 +20,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_abi.VrtConfig) == 13 * 4
     assert C.sizeof(_abi.VrtSceneParams) == 4 * (1 + 3 + 1 + 3 + 3 + 1 + 3 + 1 + 1 + 1)
     assert C.sizeof(_abi.VrtCamera) == 4 * (64 + 3 + 1 + 1 + 1 + 1)
-    assert C.sizeof(_abi.VrtStats) == 8 * 6 + 8 * 3 + 4 * 4 + 8 + 4 * 2
+    assert C.sizeof(_abi.VrtStats) == 8 * 6 + 8 * 3 + 4 * 4
 
 
 def test_no_cpu_fallback():

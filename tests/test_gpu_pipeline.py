@@ -1,7 +1,6 @@
-"""The launch pipelines around the render kernels on the GPU: the carried schedule (launches hand their unfinished paths on;
-the default), the overlapped one it replaced as the default (VRT_PIPE=overlap: dispatch gate, host release), error paths,
-frames presented asynchronously, HDR tiles written by the temporal pass, the workgroup-slot reservation of multi-GPU runs,
-and RCCL beside the library's own streams."""
+"""The launch pipeline around the render kernels on the GPU: overlapped launches (fused and one-sample ones), the dispatch
+gate and its host release, error roll-back, frames presented asynchronously, HDR tiles written by the temporal pass, the
+workgroup-slot reservation of multi-GPU runs, and RCCL beside the library's own streams."""
 import ctypes as C
 import json
 import os
@@ -47,7 +46,6 @@ def reference_frame():
 
 
 def test_overlapped_launches_with_gate(reference_frame, monkeypatch):
-    monkeypatch.setenv("VRT_PIPE", "overlap")
     hdr, st = render()
     assert st["pipeline_flags"] & 3 == 3, "overlapped launches with the dispatch gate are the default on a plain GPU box"
     assert st["pipeline_flags"] >> 8 <= 1   # only the release at context teardown may have happened
@@ -55,7 +53,6 @@ def test_overlapped_launches_with_gate(reference_frame, monkeypatch):
 
 
 def test_gate_left_out(reference_frame, monkeypatch):
-    monkeypatch.setenv("VRT_PIPE", "overlap")
     monkeypatch.setenv("VRT_DRAIN_GATE", "0")
     hdr, st = render()
     assert st["pipeline_flags"] & 3 == 1
@@ -65,7 +62,6 @@ def test_gate_left_out(reference_frame, monkeypatch):
 def test_host_release_of_the_gate_changes_nothing(reference_frame, monkeypatch):
     """The watchdog that releases a stuck dispatch gate from the host, made to fire on every synchronisation: the gate
     only times dispatches (ordering is by events), so results are the same."""
-    monkeypatch.setenv("VRT_PIPE", "overlap")
     monkeypatch.setenv("VRT_GATE_WATCHDOG_MS", "0.0001")
     mat, rgb, params = scenes.scene_sunlit(0)
     cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=DEPTH, seed=5)
@@ -81,16 +77,16 @@ def test_host_release_of_the_gate_changes_nothing(reference_frame, monkeypatch):
 
 
 def test_pipeline_depths_over_many_launches(monkeypatch):
-    """Both depths of the launch pipeline -- two launches of every workgroup slot in flight, and four launches of half the
-    slots each (the default for frames up to 1080p) -- over enough launches that every rotating resource comes round more
-    than once: 5 copies of the sample planes, 6 of the g-buffer normal / depth, 16 sets of work heads."""
-    calls = (4, 4, 3, 4, 2) * 4 + (4,) * 3
-    monkeypatch.setenv("VRT_PIPE", "overlap")
+    """The depths of the launch pipeline -- two launches of every workgroup slot in flight, four launches of half the slots
+    each (the default for frames up to 1080p), eight of a quarter each (the smallest frames, e.g. a rank's rows of an 8-GPU
+    split) -- over enough launches that every rotating resource comes round more than once: up to 9 copies of the sample
+    planes, 10 of the g-buffer normal / depth, 16 sets of work heads."""
+    calls = (4, 4, 3, 4, 2, 1, 1) * 4 + (4,) * 3
     monkeypatch.setenv("VRT_OVERLAP", "0")
     ref, st = render(calls)
     assert st["pipeline_flags"] & 1 == 0
     monkeypatch.delenv("VRT_OVERLAP")
-    for streams, div in (("4", "2"), ("2", "1"), ("4", "3")):
+    for streams, div in (("4", "2"), ("2", "1"), ("4", "3"), ("8", "4"), ("8", "2")):
         monkeypatch.setenv("VRT_STREAMS", streams)
         monkeypatch.setenv("VRT_GRID_DIV", div)
         hdr, st = render(calls)
@@ -170,7 +166,6 @@ def test_camera_ray_records_under_contention():
 def test_accumulate_failure_rolls_back(monkeypatch):
     """A launch that fails to queue (injected: VRT_TEST_FAIL_LAUNCH) returns an error, leaves nobody waiting at the dispatch
     gate, and the context renders on afterwards -- with the result of a context that never saw the failure."""
-    monkeypatch.setenv("VRT_PIPE", "overlap")
     lib = _lib.load()
     mat, rgb, params = scenes.scene_sunlit(0)
     cfg = host.make_config(320, 200, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=4, seed=2)
@@ -194,60 +189,16 @@ def test_accumulate_failure_rolls_back(monkeypatch):
     s.close()
 
 
-# ---- the carried schedule -------------------------------------------------------------------------------------------
-CARRY = 1 << 31
-
-
-def test_carried_schedule_is_the_default(reference_frame):
-    hdr, st = render()
-    assert st["pipeline_flags"] & CARRY, "launches that may be pipelined run on the carried schedule"
-    assert st["flush_launches"] >= 1          # the fetch finished what the pools held
-    assert np.array_equal(hdr.view(np.uint32), reference_frame.view(np.uint32))
-
-
 def _session(cfg, mat, rgb, params, cam=None):
     s = NativeSession(_lib.load(), "vrt_", cfg)
     orc.setup(s, mat, rgb, params, cam=cam)
     return s
 
 
-def test_carried_paths_over_many_launches(monkeypatch):
-    """Enough launches that every rotating resource of the carried schedule comes round more than once (6 output sets, 4 launch
-    tags, 16 sets of work heads), with calls of 1-4 fused samples, calls of more than 4 samples (several launches), a
-    synchronisation and a g-buffer fetch in the middle -- against the same calls with every launch finishing its own paths."""
-    from voxel_rt2_amd import _abi
-    calls = (4, 1, 3, 4, 2, 1, 1, 4, 9, 4) * 3
-
-    def run():
-        mat, rgb, params = scenes.scene_sunlit(0)
-        cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=DEPTH, seed=5)
-        s = _session(cfg, mat, rgb, params)
-        mid = None
-        for i, n in enumerate(calls):
-            s.accumulate(n)
-            if i == 7:
-                s.sync()
-            if i == 13:
-                mid = [s.fetch_buffer(b) for b in (_abi.BUF_GBUF_DEPTH, _abi.BUF_GBUF_NORMAL, _abi.BUF_GBUF_POSITION, _abi.BUF_GBUF_MAT)]
-        out = [s.fetch_hdr(), s.fetch_ldr()] + mid + [s.fetch_buffer(b) for b in (_abi.BUF_GBUF_REFL_DEPTH, _abi.BUF_HISTORY_DIFFUSE, _abi.BUF_HISTORY_SPECULAR)]
-        st = s.stats()
-        s.close()
-        return out, st
-
-    monkeypatch.setenv("VRT_OVERLAP", "0")
-    ref, st0 = run()
-    monkeypatch.delenv("VRT_OVERLAP")
-    got, st = run()
-    assert st0["pipeline_flags"] & CARRY == 0 and st["pipeline_flags"] & CARRY
-    assert np.isfinite(ref[0]).all() and ref[0].mean() > 0.01
-    for k, (a, b) in enumerate(zip(ref, got)):
-        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), k
-
-
-def test_single_sample_calls_with_a_new_jitter_each(monkeypatch):
+def test_single_sample_calls_with_a_new_jitter_each():
     """The reference's own loop shape (scene.py:177, 233-262: samples_per_frame = 1, set_proj_mat draws a new jitter every frame,
-    accumulate, copy_prev_matrices): twelve one-sample calls, a new jitter index before each -- the carried schedule keeps
-    paths of several such frames in one pool (the jitter is only read when a camera ray is set up).  Against the oracle."""
+    accumulate, copy_prev_matrices): twelve one-sample calls, a new jitter index before each, pipelined like fused launches
+    (each renders into plane 0 of a rotating copy, eight copies: the rotation comes round).  Against the oracle."""
     Wq, Hq = 320, 180
     mat, rgb, params = scenes.scene_sunlit(0)
     cfg = host.make_config(Wq, Hq, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=DEPTH, seed=11)
@@ -260,69 +211,13 @@ def test_single_sample_calls_with_a_new_jitter_each(monkeypatch):
             s.accumulate(1)
             s.end_frame()
     st = g.stats()
-    assert st["pipeline_flags"] & CARRY and st["flush_launches"] <= 2, st   # the frames really shared pools (one flush: the stats call)
+    assert st["pipeline_flags"] & 1 and st["render_launches"] == 12, st   # one-sample launches overlap too
     a, b = g.fetch_hdr(), o.fetch_hdr()
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a != b).sum()} of {a.size} values differ"
     from voxel_rt2_amd import _abi
     for which in (_abi.BUF_GBUF_DEPTH, _abi.BUF_GBUF_NORMAL, _abi.BUF_GBUF_MAT, _abi.BUF_HISTORY_DIFFUSE, _abi.BUF_HISTORY_SPECULAR):
         assert np.array_equal(g.fetch_buffer(which).view(np.uint8), o.fetch_buffer(which).view(np.uint8)), which
     g.close(); o.close()
-
-
-def test_scene_and_camera_changes_flush_the_carried_paths():
-    """Paths in the pools read the scene parameters and the camera of the launch they were begun in: a change of either (not
-    of the jitter alone) first finishes them under the old values.  Sun moved, floor recoloured, camera moved between calls --
-    against the oracle."""
-    Wq, Hq = 256, 160
-    from voxel_rt2_amd import camera
-    mat, rgb, params = scenes.scene_sunlit(0)
-    cfg = host.make_config(Wq, Hq, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=DEPTH, seed=21)
-    g, o = _session(cfg, mat, rgb, params), orc.Oracle(cfg, threads=16)
-    orc.setup(o, mat, rgb, params)
-    p2 = dict(params, light_direction=(0.3, 1.0, -0.5), floor_color=(0.4, 0.7, 0.9))
-    pos = (0.5, 0.55, 1.9)
-    view, proj = camera.default_matrices(Wq, Hq, pos=pos)
-    for s in (g, o):
-        s.accumulate(4); s.accumulate(2)
-        s.set_scene(host.make_scene_params(**p2))
-        s.accumulate(4); s.accumulate(1)
-        s.end_frame()
-        s.set_camera(host.make_camera(view, proj, pos, jitter_index=5))
-        s.reset()
-        s.accumulate(4); s.accumulate(3)
-    assert g.stats()["flush_launches"] >= 3
-    a, b = g.fetch_hdr(), o.fetch_hdr()
-    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a != b).sum()} of {a.size} values differ"
-    g.close(); o.close()
-
-
-def test_carried_schedule_after_a_failed_launch(monkeypatch):
-    """A launch that fails to queue on the carried schedule: the error is reported, the passes of the calls still waiting for
-    their paths are dropped with them (documented: the history is then undefined and the caller resets it), and the context
-    renders on -- what the oracle renders for the same calls without the failed one."""
-    lib = _lib.load()
-    mat, rgb, params = scenes.scene_sunlit(0)
-    cfg = host.make_config(320, 200, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=4, seed=2)
-    monkeypatch.setenv("VRT_TEST_FAIL_LAUNCH", "2")
-    s = NativeSession(lib, "vrt_", cfg)
-    monkeypatch.delenv("VRT_TEST_FAIL_LAUNCH")
-    orc.setup(s, mat, rgb, params)
-    s.accumulate(4)
-    s.accumulate(4)
-    assert lib.vrt_accumulate(C.c_void_p(s._ctx), 4) == -2 and b"injected" in lib.vrt_last_error()
-    s.reset()
-    for n in (4, 1, 4):
-        s.accumulate(n)
-    o = orc.Oracle(cfg, threads=16)
-    orc.setup(o, mat, rgb, params)
-    for n in (4, 4):
-        o.accumulate(n)
-    o.reset()
-    for n in (4, 1, 4):
-        o.accumulate(n)
-    assert s.stats()["pipeline_flags"] & CARRY
-    assert np.array_equal(s.fetch_hdr().view(np.uint32), o.fetch_hdr().view(np.uint32))
-    s.close(); o.close()
 
 
 def test_frames_presented_asynchronously():
@@ -367,8 +262,8 @@ def test_hdr_tiles_written_by_the_temporal_pass():
     for k in range(10):
         a.accumulate(4 if k % 3 else 2)
         n = a.hdr_targets_written()
-        assert n <= k + 1 and n >= k + 1 - 3     # at most three calls behind
-        if n > seen:
+        assert n == k + 1                        # the call queues its own tile
+        if n > seen and k % 4 == 3:
             a.sync()                             # (a gather would wait on an event of the context's stream instead)
             for j in range(seen, a.hdr_targets_written()):
                 got.append(ring[j % 8].cpu().numpy().copy())
@@ -432,7 +327,7 @@ def test_rccl_beside_the_library():
     r = subprocess.run([sys.executable, "-c", code, str(port)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert out == dict(same=True, backend="nccl", queues="8")
+    assert out == dict(same=True, backend="nccl", queues="16")
 
 
 def test_sky_precompute_split_by_columns_on_the_gpu():

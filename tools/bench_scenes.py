@@ -30,6 +30,8 @@ CASES = [
     # one rank's share of an 8- and a 2-GPU run of config 2 (rows through the middle of the picture)
     dict(name="shard_1of8_config2", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=20, rows=(472, 607)),
     dict(name="shard_1of2_config2", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=20, rows=(0, 540)),
+    # the reference's own loop shape: one sample per call, a new jitter and vrt_end_frame every frame (scene.py:177, 233-262)
+    dict(name="scene_api_default_1080p", scene="s1", W=1920, H=1080, depth=8, spp=1, steps=120, per_frame_camera=True),
 ]
 
 
@@ -70,14 +72,29 @@ def run(case):
     s.sync()
     lib.vrt_reset_stats(C.c_void_p(s._ctx))
     t0 = time.perf_counter()
-    fetch_each = bool(os.environ.get("VRT_BENCH_FETCH_EACH"))  # the PCIe-inclusive rate: the HDR frame copied to host memory after every step
+    # the PCIe-inclusive rate: the frame copied to host memory after every step.  1: blocking vrt_fetch_hdr into pageable memory;
+    # "async": vrt_fetch_ldr_async (tonemap + copy on the library's fetch stream) into two page-locked buffers, the caller
+    # collecting frame k - 1 while frame k renders -- the reference's accumulate / fetch_image loop (scene.py:255-262)
+    fetch_each = os.environ.get("VRT_BENCH_FETCH_EACH", "")
     sync_each = bool(os.environ.get("VRT_BENCH_SYNC_EACH"))   # a caller that looks at every frame: no two launches in flight
-    for _ in range(case["steps"]):
+    pinned = [s.host_alloc((case["H"], case["W"], 4)) for _ in range(2)] if fetch_each == "async" else None
+    cams = [host.default_camera(case["W"], case["H"], jitter_index=k + 1) for k in range(16)] if case.get("per_frame_camera") else None
+    for k in range(case["steps"]):
+        if cams:
+            s.set_camera(cams[k % 16])
         s.accumulate(case["spp"])
+        if cams:
+            s.end_frame()
         if sync_each:
             s.sync()
-        if fetch_each:
+        if fetch_each == "async":
+            s.fetch_ldr_async(pinned[k % 2], slot=k % 2)
+            if k:
+                s.fetch_wait((k - 1) % 2)
+        elif fetch_each:
             s.fetch_hdr()
+    if fetch_each == "async":
+        s.fetch_wait((case["steps"] - 1) % 2)
     s.sync()
     dt = time.perf_counter() - t0
     st = s.stats()

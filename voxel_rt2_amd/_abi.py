@@ -42,7 +42,6 @@ class VrtStats(C.Structure):
         ("render_ms", C.c_double), ("temporal_ms", C.c_double), ("gris_ms", C.c_double),
         ("render_launches", C.c_uint32), ("temporal_launches", C.c_uint32), ("gris_launches", C.c_uint32),
         ("pipeline_flags", C.c_uint32),
-        ("flush_ms", C.c_double), ("flush_launches", C.c_uint32), ("reserved0", C.c_uint32),
     ]
 
     def as_dict(self):

@@ -39,12 +39,14 @@ def _share_hip_runtime_with_torch():
                 return
 
 
-def _want_hw_queues(n=8):
-    """The library renders on two streams of its own beside the caller's; a multi-GPU rank adds a gather stream and RCCL's.
-    The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams that share a
-    queue serialise: a wait queued for the gather then holds back the next render launch (one rank's share of an 8-way
-    split: 0.418 ms per step with 4 queues, 0.317 with 8).  The variable is read when the runtime starts, so it is set
-    here, before libvrt_hip.so (or torch) initialises HIP -- unless the user chose a value."""
+def _want_hw_queues(n=16):
+    """The library renders on up to eight streams of its own beside the caller's (vrt_api.hip, ensure_overlap); a multi-GPU
+    rank adds a gather stream and RCCL's.  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
+    (default 4) and two streams that share a queue serialise: a wait queued for the gather then holds back the next render
+    launch (one rank's share of an 8-way split: 0.418 ms per step with 4 queues, 0.317 with 8; the eight-launch pipeline the
+    library uses on such small frames wants 16).  The variable is read when the runtime starts, so it is set here -- a
+    process-wide side effect: torch and child processes see it too -- before libvrt_hip.so (or torch) initialises HIP, unless
+    the user chose a value (any value: set GPU_MAX_HW_QUEUES yourself to opt out)."""
     import sys
     import warnings
     if "GPU_MAX_HW_QUEUES" in os.environ:
@@ -57,7 +59,7 @@ def _want_hw_queues(n=8):
         up = False
     if up:
         warnings.warn("voxel_rt2_amd: the HIP runtime was initialised before the library was loaded, so it keeps its default of "
-                      "4 hardware queues; export GPU_MAX_HW_QUEUES=8 (or import voxel_rt2_amd first) for multi-GPU runs",
+                      "4 hardware queues; export GPU_MAX_HW_QUEUES=16 (or import voxel_rt2_amd first) for multi-GPU runs",
                       RuntimeWarning, stacklevel=3)
 
 

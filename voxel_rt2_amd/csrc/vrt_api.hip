@@ -10,7 +10,6 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
-#include <deque>
 #include <string>
 #include <thread>
 #include <vector>
@@ -18,18 +17,11 @@
 #include "vrt_kernels.h"
 
 #define VRT_MAX_FUSED 4   // samples of one vrt_accumulate(n) call rendered by a single launch
-#define VRT_MAX_STREAMS 4 // render launches in flight at most (a stream, a pool scratch and a camera-ray table each): 2 or 4 are used
-#define VRT_MAX_SETS 5    // copies of what a render launch writes (set 0 = the canonical buffers): streams + 1 are used
+#define VRT_MAX_STREAMS 8 // render launches in flight at most (a stream, a pool scratch and a camera-ray table each): 2, 4 or 8 are used
+#define VRT_MAX_SETS 9    // copies of what a render launch writes (set 0 = the canonical buffers): streams + 1 are used
 #define VRT_GB_ROT (VRT_MAX_SETS + 1)   // rotating g-buffer normal / depth copies: copy j is read by temporal passes j and j + 1, and the
                                        // launch that writes it again only waits for the pass VRT_MAX_SETS launches back
 #define VRT_WORK_SETS 16  // rotating sets of work heads (vrt_kernels.hip: a launch zeroes the set eight launches ahead)
-// The carried schedule (accumulate_carry): render launches follow one another on ONE stream and hand their unfinished paths
-// on (CarryArgs, vrt_kernels.hip).  A path begun in launch k ends in launch k + VRT_CARRY_LAG at the latest, so temporal
-// pass k runs after that launch; set k % VRT_CARRY_SETS of the output arrays is written again by launch k + VRT_CARRY_SETS,
-// which waits for pass k + 1 (the last reader of set k: it takes its g-buffer as "previous") -- queued after launch
-// k + 1 + VRT_CARRY_LAG, hence SETS > LAG + 2.
-#define VRT_CARRY_LAG 3
-#define VRT_CARRY_SETS 6
 #define VRT_FETCH_SLOTS 4 // asynchronous fetches the caller may have outstanding (vrt_fetch_*_async)
 
 using namespace vrt;
@@ -43,20 +35,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
             return fail(VRT_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));               \
     } while (0)
 
-struct vrt_ctx;
-static int carry_flush(vrt_ctx* c);   // finish the paths the carried schedule keeps between launches, queue their temporal passes
-#define FLUSH_TRY(c) do { if (carry_flush(c) != VRT_OK) return VRT_E_DEVICE; } while (0)
-
-struct EventPair { hipEvent_t a, b; int kind; };  // kind 0 render, 1 temporal, 2 gris, 3 flush of the carried schedule
-
-// a temporal pass of the carried schedule, queued VRT_CARRY_LAG launches after its render launch (or at the flush)
-struct PendingPass {
-    FrameParams fp;
-    int set, g;
-    bool last_of_call;   // the pass that completes a vrt_accumulate call: it also writes the caller's HDR tile (vrt_set_hdr_targets)
-    const uint32_t* prev_normal; const float* prev_depth;
-    mat4 prev_view, prev_proj;
-};
+struct EventPair { hipEvent_t a, b; int kind; };  // kind 0 render, 1 temporal, 2 gris
 
 struct vrt_ctx {
     vrt_config cfg;
@@ -133,6 +112,7 @@ struct vrt_ctx {
     // that once and leaves the gate out where the test fails.
     uint32_t* drain_signal = nullptr;
     bool drain_signalled = false;  // the most recent render launch was given the signal
+    bool prev_launch_full = true;  // ... and took every workgroup slot (the next dispatch waits for ITS drain, whatever the pipeline's depth)
     unsigned gate_releases = 0;    // host releases so far (error paths, watchdog): diagnostic
     hipStream_t rstream[VRT_MAX_STREAMS] = {};
     hipEvent_t ev_r[VRT_MAX_SETS] = {}, ev_t[VRT_MAX_SETS] = {}, ev_main = nullptr;
@@ -142,22 +122,6 @@ struct vrt_ctx {
     unsigned pipe_seq = 0;    // overlapped launches so far
     int last_set = 0;         // copy (0 = the canonical buffers) the most recent render launch wrote
     int last_render_set = -1; // copy whose ev_r the most recent overlapped launch recorded (-1: none yet)
-    // the carried schedule (accumulate_carry)
-    bool carry_ready = false, carry_failed = false;
-    f3 *cs_color_d = nullptr, *cs_color_s = nullptr, *cs_gb_pos = nullptr;   // [SETS][VRT_MAX_FUSED][npix] x2, [SETS][npix]
-    float *cs_refl = nullptr, *cs_gb_depth = nullptr;                        // [SETS][VRT_MAX_FUSED][npix], [SETS][npix]
-    uint32_t *cs_gb_mat = nullptr, *cs_gb_normal = nullptr;                  // [SETS][npix]
-    uint32_t* d_carry_state = nullptr;   // the pools between launches (pool_carry_bytes)
-    int carry_blocks = 0;                // grid the state was laid out for
-    PrimaryRecord* d_carry_prim = nullptr;
-    hipStream_t carry_stream = nullptr;
-    hipEvent_t ev_cr[VRT_CARRY_SETS] = {}, ev_ct[VRT_CARRY_SETS] = {};
-    bool ev_ct_valid[VRT_CARRY_SETS] = {};
-    unsigned carry_seq = 0;              // carried launches so far: launch k writes set k % VRT_CARRY_SETS
-    std::deque<PendingPass> carry_pending;   // non-empty <=> paths may be in the pools
-    FrameParams carry_fp{}; SceneData carry_sc{}; bool carry_cull = false;   // what the carried paths were launched with
-    bool canon_in_carry = false;         // the newest specular / reflection-depth / position / material planes are a carry set's
-    int carry_last_set = 0, carry_last_g = 1;
     const uint32_t* last_gb_normal = nullptr;   // g-buffer normal / depth of the most recent render launch (either schedule)
     const float* last_gb_depth = nullptr;
     // HDR tiles handed over device to device (vrt_set_hdr_targets): pass k also writes its HDR rows to ring[k % n]
@@ -247,8 +211,7 @@ static void resolve_events(vrt_ctx* c) {
         if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
             if (ev.kind == 0) { c->stats.render_ms += ms; c->stats.render_launches++; }
             else if (ev.kind == 1) { c->stats.temporal_ms += ms; c->stats.temporal_launches++; }
-            else if (ev.kind == 2) { c->stats.gris_ms += ms; c->stats.gris_launches++; }
-            else { c->stats.flush_ms += ms; c->stats.flush_launches++; }
+            else { c->stats.gris_ms += ms; c->stats.gris_launches++; }
         }
         hipEventDestroy(ev.a);
         hipEventDestroy(ev.b);
@@ -374,7 +337,7 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
     ok = ok && dalloc(&c->d_mat, nvox) == hipSuccess && dalloc(&c->d_rgb, nvox * 3) == hipSuccess && dalloc(&c->d_grid, nvox) == hipSuccess;
     ok = ok && dalloc(&c->d_l0, nw0) == hipSuccess && dalloc(&c->d_l1, nw1) == hipSuccess && dalloc(&c->d_l2, nw2) == hipSuccess &&
          dalloc(&c->d_l3, 1) == hipSuccess && dalloc(&c->d_cull, 16) == hipSuccess && dalloc(&c->d_l0c, 32768) == hipSuccess && dalloc(&c->d_l0c_base, 513) == hipSuccess;
-    ok = ok && dalloc(&c->d_mats, 128 * 14) == hipSuccess && dalloc(&c->d_counters, 1) == hipSuccess && dalloc(&c->d_work, VRT_WORK_SETS * (VRT_WORK_HEADS + 1) * VRT_WORK_HEAD_STRIDE) == hipSuccess;   // heads, then a flag line per set (CarryArgs::announce)
+    ok = ok && dalloc(&c->d_mats, 128 * 14) == hipSuccess && dalloc(&c->d_counters, 1) == hipSuccess && dalloc(&c->d_work, VRT_WORK_SETS * VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE) == hipSuccess;
     ok = ok && dalloc(&c->d_cbuf[0], n) == hipSuccess && dalloc(&c->d_cbuf[1], n) == hipSuccess && dalloc(&c->d_spec_planes, n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->d_gb_pos, n) == hipSuccess;
     ok = ok && dalloc(&c->d_gb_mat, n) == hipSuccess && dalloc(&c->d_refl_planes, n * VRT_MAX_FUSED) == hipSuccess;
     if (ok) { c->d_color_s = c->d_spec_planes + (size_t)(VRT_MAX_FUSED - 1) * n; c->d_gb_refl = c->d_refl_planes + (size_t)(VRT_MAX_FUSED - 1) * n; }
@@ -424,8 +387,6 @@ void vrt_destroy(vrt_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     release_gate(c);   // nothing may be left waiting at a gate
-    (void)carry_flush(c);   // every wave of every launch reaches its exit whatever the pools hold; this only keeps the last passes
-    if (c->carry_stream) hipStreamSynchronize(c->carry_stream);
     if (c->fetch_stream) hipStreamSynchronize(c->fetch_stream);
     for (int s = 0; s < VRT_MAX_STREAMS; s++) if (c->rstream[s]) hipStreamSynchronize(c->rstream[s]);
     if (c->stream) hipStreamSynchronize(c->stream);
@@ -436,17 +397,10 @@ void vrt_destroy(vrt_ctx* c) {
     }
     for (int s = 0; s < VRT_MAX_STREAMS; s++) if (c->rstream[s]) hipStreamDestroy(c->rstream[s]);
     if (c->ev_main) hipEventDestroy(c->ev_main);
-    for (int s = 0; s < VRT_CARRY_SETS; s++) { if (c->ev_cr[s]) hipEventDestroy(c->ev_cr[s]); if (c->ev_ct[s]) hipEventDestroy(c->ev_ct[s]); }
     for (int s = 0; s < VRT_FETCH_SLOTS; s++) if (c->ev_fetch[s]) hipEventDestroy(c->ev_fetch[s]);
     for (int s = 0; s < 2; s++) if (c->ev_cbuf_read[s]) hipEventDestroy(c->ev_cbuf_read[s]);
     if (c->ev_fetch_src) hipEventDestroy(c->ev_fetch_src);
-    if (c->carry_stream) hipStreamDestroy(c->carry_stream);
     if (c->fetch_stream) hipStreamDestroy(c->fetch_stream);
-    {
-        void* carry[] = {c->cs_color_d, c->cs_color_s, c->cs_refl, c->cs_gb_pos, c->cs_gb_mat, c->cs_gb_normal, c->cs_gb_depth, c->d_carry_state, c->d_carry_prim};
-        for (void* p : carry)
-            if (p) hipFree(p);
-    }
     if (c->drain_signal) hipFree(c->drain_signal);
     for (int s = 0; s < VRT_MAX_STREAMS; s++) {
         if (c->d_prim_cache[s]) hipFree(c->d_prim_cache[s]);
@@ -476,7 +430,6 @@ void vrt_destroy(vrt_ctx* c) {
 int vrt_upload_voxels(vrt_ctx* c, const int8_t* mat, const uint8_t* rgb) {
     if (!c || !mat || !rgb) return fail(VRT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);   // (paths in flight read the scene)
     const size_t nvox = (size_t)c->cfg.grid_res * c->cfg.grid_res * c->cfg.grid_res;
     HIP_TRY(hipMemcpyAsync(c->d_mat, mat, nvox, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_rgb, rgb, nvox * 3, hipMemcpyHostToDevice, c->stream));
@@ -488,7 +441,6 @@ int vrt_upload_voxels(vrt_ctx* c, const int8_t* mat, const uint8_t* rgb) {
 int vrt_upload_materials(vrt_ctx* c, const float* table) {
     if (!c || !table) return fail(VRT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     c->main_dirty = true;
     HIP_TRY(hipMemcpyAsync(c->d_mats, table, 128 * 14 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_mat_derived(c->stream, c->d_mats, c->d_mats_x));
@@ -499,7 +451,6 @@ int vrt_upload_cloud_texture(vrt_ctx* c, const uint8_t* rgb) {
     if (!c || !rgb) return fail(VRT_E_INVALID, "null argument");
     if (c->cfg.sky_res <= 0) return fail(VRT_E_STATE, "context was created without sky tables (sky_res = 0)");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     c->main_dirty = true;
     HIP_TRY(hipMemcpyAsync(c->d_cloud_tex, rgb, 256 * 256 * 3, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(sync_guarded(c, c->stream));
@@ -525,7 +476,6 @@ int vrt_reserve_cus(vrt_ctx* c, int n_cus) {
     if (!c || n_cus < 0) return fail(VRT_E_INVALID, "bad argument");
     if (n_cus > c->n_cu - 8) n_cus = c->n_cu - 8 > 0 ? c->n_cu - 8 : 0;
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);   // (the pools are laid out for the grid)
     c->reserved_cus = n_cus;
     c->render_blocks = 0;   // the grid is sized again at the next vrt_accumulate
     return VRT_OK;
@@ -533,7 +483,6 @@ int vrt_reserve_cus(vrt_ctx* c, int n_cus) {
 int vrt_set_instrumented(vrt_ctx* c, int on) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     c->instrumented = on != 0;
     c->count_as_timed = on == 2;
     c->render_blocks = 0;
@@ -543,7 +492,6 @@ int vrt_set_instrumented(vrt_ctx* c, int on) {
 int vrt_prepare(vrt_ctx* c) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     c->main_dirty = true;
     HIP_TRY(launch_prepare(c->stream, c->cfg.grid_res, c->d_mat, c->d_rgb, c->d_grid, c->d_l0, c->d_l1, c->d_l2, c->d_l3, c->d_l0c, c->d_l0c_base, c->d_cull));
     {
@@ -572,7 +520,6 @@ int vrt_sky_accumulate_clouds(vrt_ctx* c, int max_samples) {
     if (!c || max_samples <= 0) return fail(VRT_E_INVALID, "bad argument");
     if (!c->prepared || c->scene.use_physical_sky != 1) return fail(VRT_E_STATE, "needs vrt_prepare with use_physical_sky");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     f3 sd, sc_;
     float cm;
     sun_of(c, sd, sc_, cm);
@@ -588,7 +535,6 @@ int vrt_sky_accumulate_clouds_slice(vrt_ctx* c, int max_samples, int slice_idx, 
     if (!c || max_samples <= 0 || max_slices <= 0 || slice_idx < 0 || slice_idx >= max_slices) return fail(VRT_E_INVALID, "bad argument");
     if (!c->prepared || c->scene.use_physical_sky != 1) return fail(VRT_E_STATE, "needs vrt_prepare with use_physical_sky");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     f3 sd, sc_;
     float cm;
     sun_of(c, sd, sc_, cm);
@@ -608,7 +554,6 @@ int vrt_sky_table_io(vrt_ctx* c, int which, int u0, int u1, void* device_ptr, in
     if (which != VRT_BUF_SKY_SCATTERING && which != VRT_BUF_SKY_TRANSMITTANCE) return fail(VRT_E_INVALID, "not a sky table");
     if (u0 < 0 || u1 > c->cfg.sky_res || u1 <= u0) return fail(VRT_E_INVALID, "column range outside the table");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     float* table = which == VRT_BUF_SKY_SCATTERING ? c->d_sky_scat : c->d_sky_trans;
     const size_t col = (size_t)c->cfg.sky_res * 3 * sizeof(float);
     char* lib = (char*)table + (size_t)u0 * col;
@@ -622,7 +567,6 @@ int vrt_sky_compute_slice(vrt_ctx* c, int slice_idx, int max_slices) {
     if (!c || max_slices <= 0 || slice_idx < 0 || slice_idx >= max_slices) return fail(VRT_E_INVALID, "bad slice");
     if (!c->prepared || c->scene.use_physical_sky != 1) return fail(VRT_E_STATE, "needs vrt_prepare with use_physical_sky");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     f3 sd, sc_;
     float cm;
     sun_of(c, sd, sc_, cm);
@@ -655,10 +599,20 @@ static bool ensure_overlap(vrt_ctx* c) {
     // VRT_DEEP_ITEMS: largest launch (pixels x fused samples) that gets the deep pipeline; VRT_STREAMS / VRT_GRID_DIV override.
     size_t deep_items = (size_t)12 << 20;
     if (const char* e = getenv("VRT_DEEP_ITEMS")) deep_items = (size_t)atoll(e);
-    const bool deep = (size_t)c->cfg.width * (size_t)(c->own1 - c->own0) * VRT_MAX_FUSED <= deep_items;
-    c->n_streams = deep ? 4 : 2;
-    c->grid_div = deep ? 2 : 1;
-    if (const char* e = getenv("VRT_STREAMS")) { const int v = atoi(e); if (v == 2 || v == 4) c->n_streams = v; }
+    const size_t items = (size_t)c->cfg.width * (size_t)(c->own1 - c->own0) * VRT_MAX_FUSED;
+    const bool deep = items <= deep_items;
+    // Deeper still for the smallest frames -- one rank's rows of an 8-GPU split of 1080p are 1 M items a launch: eight launches
+    // of a quarter of the slots each (profiles/r02_pipeline_depth.txt: +7.5 % on those rows, +1 % on half a frame, nothing on a
+    // whole one).  Each render stream wants a hardware queue of its own (two streams on one queue serialise), so only where
+    // the runtime was started with sixteen (GPU_MAX_HW_QUEUES, which voxel_rt2_amd/_lib.py sets unless the user has).
+    size_t deeper_items = (size_t)5 << 19;   // 2.5 M
+    if (const char* e = getenv("VRT_DEEPER_ITEMS")) deeper_items = (size_t)atoll(e);
+    int hw_queues = 4;
+    if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hw_queues = atoi(e);
+    const bool deeper = deep && items <= deeper_items && hw_queues >= 16;
+    c->n_streams = deeper ? 8 : deep ? 4 : 2;
+    c->grid_div = deeper ? 4 : deep ? 2 : 1;
+    if (const char* e = getenv("VRT_STREAMS")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) c->n_streams = v; }
     if (const char* e = getenv("VRT_GRID_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 4) c->grid_div = v; }
     const int n_sets = c->n_streams + 1;
     bool ok = true;
@@ -693,26 +647,20 @@ static bool ensure_overlap(vrt_ctx* c) {
 // After a failed queue operation inside vrt_accumulate: nothing may be left waiting for a launch that did not happen, and
 // the context must be usable again.  The rotation state (buffer roles, frame index, pipeline slot) only advances at the end
 // of an iteration whose launches were all queued, so a context without ReSTIR on the overlapped or plain schedule is back at
-// the pass before the failed one.  NOT so the accumulated history in two cases, after which the caller must vrt_reset():
-// a fused ReSTIR call (its per-sample reuse and accumulation passes ping-pong the histories in place, so the passes queued
-// before the failure have advanced them while the roles were rolled back), and the carried schedule (the passes of up to
-// VRT_CARRY_LAG earlier calls were still waiting for their paths and are dropped with them).
+// the pass before the failed one.  NOT so the accumulated history of a fused ReSTIR call: its per-sample reuse and
+// accumulation passes ping-pong the histories in place, so the passes queued before the failure have advanced them while
+// the roles were rolled back -- after a failed call on a ReSTIR context the caller must vrt_reset().
 static void abort_pipeline(vrt_ctx* c) {
     const std::string keep = g_err;
     release_gate(c);
     c->drain_signalled = false;
     for (int s = 0; s < VRT_MAX_STREAMS; s++) if (c->rstream[s]) (void)hipStreamSynchronize(c->rstream[s]);
-    if (c->carry_stream) (void)hipStreamSynchronize(c->carry_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipGetLastError();
-    // the carried schedule: the passes still waiting for their launches are dropped with the paths in the pools
-    c->carry_pending.clear();
-    if (c->d_carry_state) (void)hipMemset(c->d_carry_state, 0, pool_carry_bytes(c->cfg.grid_res, c->carry_blocks));
-    for (int s = 0; s < VRT_CARRY_SETS; s++) c->ev_ct_valid[s] = false;
     resolve_events(c);
     // the work heads rotate with the launch number and each launch zeroes the set eight launches ahead: a launch that did not
     // run leaves a used set behind -- nothing is in flight now, so all of them start clean
-    (void)hipMemset(c->d_work, 0, VRT_WORK_SETS * (VRT_WORK_HEADS + 1) * VRT_WORK_HEAD_STRIDE * sizeof(unsigned));
+    (void)hipMemset(c->d_work, 0, VRT_WORK_SETS * VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE * sizeof(unsigned));
     (void)hipStreamSynchronize(nullptr);   // (the fill runs on the NULL stream: see dalloc)
     (void)hipGetLastError();
     for (int s = 0; s < VRT_MAX_SETS; s++) c->ev_t_valid[s] = false;
@@ -722,41 +670,6 @@ static void abort_pipeline(vrt_ctx* c) {
 }
 
 
-// ---- the carried schedule ------------------------------------------------------------------------------------------
-// A persistent launch ends in a tail: when the work runs out every wave still has a pool of paths with up to max_depth bounces
-// to go, at falling occupancy -- 0.2 ms whatever the frame's size, which is most of a launch for one rank's rows of an 8-GPU
-// split or for the reference's one-sample-per-call loop (scene.py:255-256).  Overlapping launches hides part of that at the
-// price of smaller launches.  Here there is no tail: a wave that finds the work used up SAVES its pool and leaves, and the
-// wave in the same place of the next launch goes on with those paths beside the new launch's.  Every path still writes to
-// the buffers of the launch it was begun in (set = launch % VRT_CARRY_SETS, CarryRef), ends within VRT_CARRY_LAG launches,
-// and the temporal pass of launch k is queued behind launch k + VRT_CARRY_LAG; a synchronisation, a fetch or a change of
-// camera / scene first runs a launch without new work that finishes what is in the pools (carry_flush).  Static camera at
-// full render scale, ReSTIR off (its reuse pass needs every path of the launch): exactly the launches the overlapped
-// pipeline took.  Paths, random streams and output pixels are what they were: results do not change by a bit.
-static bool ensure_carry(vrt_ctx* c) {
-    if (c->carry_ready) return true;
-    if (c->carry_failed) return false;
-    const size_t n = c->npix, NS = VRT_CARRY_SETS;
-    bool ok = dalloc(&c->cs_color_d, NS * VRT_MAX_FUSED * n) == hipSuccess && dalloc(&c->cs_color_s, NS * VRT_MAX_FUSED * n) == hipSuccess &&
-              dalloc(&c->cs_refl, NS * VRT_MAX_FUSED * n) == hipSuccess && dalloc(&c->cs_gb_pos, NS * n) == hipSuccess &&
-              dalloc(&c->cs_gb_mat, NS * n) == hipSuccess && dalloc(&c->cs_gb_normal, NS * n) == hipSuccess &&
-              dalloc(&c->cs_gb_depth, NS * n) == hipSuccess && dalloc(&c->d_carry_prim, n) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->carry_stream, hipStreamNonBlocking) == hipSuccess;
-    for (int s = 0; s < VRT_CARRY_SETS && ok; s++)
-        ok = hipEventCreateWithFlags(&c->ev_cr[s], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_ct[s], hipEventDisableTiming) == hipSuccess;
-    if (ok && !c->ev_main) ok = hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); c->carry_failed = true; return false; }
-    c->carry_ready = true;
-    return true;
-}
-static PixelBuffers carry_out(const vrt_ctx* c) {   // set 0 of the per-set arrays; a path adds its set's offset (CarryRef)
-    PixelBuffers out;
-    out.color_d = c->cs_color_d; out.color_s = c->cs_color_s; out.gb_refl_depth = c->cs_refl;
-    out.gb_normal = c->cs_gb_normal; out.gb_depth = c->cs_gb_depth; out.gb_position = c->cs_gb_pos; out.gb_mat = c->cs_gb_mat;
-    out.reservoir = nullptr;
-    out.sample_stride = (int)c->npix;
-    return out;
-}
 // rows of the HDR frame a pass also writes to the caller's ring (vrt_set_hdr_targets)
 static f3* next_hdr_target(vrt_ctx* c) {
     if (c->hdr_targets.empty()) return nullptr;
@@ -764,116 +677,6 @@ static f3* next_hdr_target(vrt_ctx* c) {
 }
 static int wait_cbuf_readers(vrt_ctx* c, int b) {   // an asynchronous fetch may still be reading the HDR buffer a pass is about to write
     if (c->cbuf_read_pending[b]) { HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_cbuf_read[b], 0)); c->cbuf_read_pending[b] = false; }
-    return VRT_OK;
-}
-// the temporal pass of a carried launch, on the context's stream behind `after` (the launch that ended its last paths)
-static int emit_pass(vrt_ctx* c, const PendingPass& pp, hipEvent_t after) {
-    const size_t n = c->npix;
-    HIP_TRY(hipStreamWaitEvent(c->stream, after, 0));
-    TemporalBuffers tb;
-    tb.color_d = c->cs_color_d + (size_t)pp.set * VRT_MAX_FUSED * n; tb.color_s = c->cs_color_s + (size_t)pp.set * VRT_MAX_FUSED * n;
-    tb.gb_normal = c->cs_gb_normal + (size_t)pp.set * n; tb.gb_depth = c->cs_gb_depth + (size_t)pp.set * n; tb.gb_mat = c->cs_gb_mat + (size_t)pp.set * n;
-    tb.gb_refl_raw = c->cs_refl + (size_t)pp.set * VRT_MAX_FUSED * n; tb.gb_refl_filtered = c->d_gb_refl_f;
-    tb.hist_d_in = c->d_hist_d[c->hist_in]; tb.hist_d_out = c->d_hist_d[c->hist_in ^ 1];
-    tb.hist_s_in = c->d_hist_s[c->hist_in]; tb.hist_s_out = c->d_hist_s[c->hist_in ^ 1];
-    tb.prev_normal = pp.prev_normal; tb.prev_depth = pp.prev_depth;
-    tb.hdr = c->d_cbuf[c->cidx ^ 1];
-    tb.sample_stride = (int)n;
-    tb.prev_view = pp.prev_view; tb.prev_proj = pp.prev_proj;
-    tb.tile = pp.last_of_call ? next_hdr_target(c) : nullptr; tb.tile_row0 = c->own0;
-    if (wait_cbuf_readers(c, c->cidx ^ 1) != VRT_OK) return VRT_E_DEVICE;
-    hipEvent_t a, b;
-    if (record(c, 1, &a, &b) != VRT_OK) return VRT_E_DEVICE;
-    HIP_TRY(hipEventRecord(a, c->stream));
-    HIP_TRY(launch_temporal(c->stream, pp.fp, tb, c->own0, c->own1, pp.g));
-    HIP_TRY(hipEventRecord(b, c->stream));
-    HIP_TRY(hipEventRecord(c->ev_ct[pp.set], c->stream));
-    c->ev_ct_valid[pp.set] = true;
-    c->hist_in ^= 1; c->cidx ^= 1;   // pathtracer.py:1298-1303 copy loop == pointer swaps, once per accumulation pass
-    return VRT_OK;
-}
-// Finish what the pools hold (a launch without new work) and queue the temporal passes that were waiting for it.
-static int carry_flush(vrt_ctx* c) {
-    if (c->carry_pending.empty()) return VRT_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    const int slot = (int)(c->carry_seq % VRT_CARRY_SETS);   // the flush counts as the next launch; it begins no path, so it writes no set
-    hipEvent_t a, b;
-    if (record(c, 3, &a, &b) != VRT_OK) return VRT_E_DEVICE;
-    HIP_TRY(hipEventRecord(a, c->carry_stream));
-    const unsigned seq = c->launch_seq++;
-    HIP_TRY(launch_render_pool_carry(c->carry_stream, c->cfg.grid_res, c->carry_blocks, c->carry_fp, c->carry_sc, carry_out(c), c->d_work, seq, 1,
-                                     c->d_pool_scratch, nullptr, c->carry_cull, c->d_carry_state, (int)c->npix, (int)(c->npix * VRT_MAX_FUSED),
-                                     VRT_CARRY_SETS, slot, true, false));
-    HIP_TRY(hipEventRecord(b, c->carry_stream));
-    HIP_TRY(hipEventRecord(c->ev_cr[slot], c->carry_stream));
-    while (!c->carry_pending.empty()) {
-        const PendingPass pp = c->carry_pending.front();
-        c->carry_pending.pop_front();
-        if (emit_pass(c, pp, c->ev_cr[slot]) != VRT_OK) return VRT_E_DEVICE;
-    }
-    return VRT_OK;
-}
-// what must be equal for paths of two launches to share a pool: everything but the frame number and the jitter, which only
-// the set-up of a camera ray reads (path_begin)
-static bool carry_compatible(const vrt_ctx* c, const FrameParams& fp, const SceneData& sc, bool cull) {
-    FrameParams x = fp, y = c->carry_fp;
-    x.frame = y.frame = 0u;
-    x.taa_jitter = y.taa_jitter = mk2(0.0f, 0.0f);
-    return memcmp(&x, &y, sizeof(x)) == 0 && memcmp(&sc, &c->carry_sc, sizeof(sc)) == 0 && cull == c->carry_cull;
-}
-// one render launch of g fused samples on the carried schedule
-static int accumulate_carry(vrt_ctx* c, int g, bool last_of_call) {
-    FrameParams fp = make_frame_params(c);
-    SceneData sc = make_scene_data(c);
-    const bool cull = culling(c);
-    if (!c->carry_pending.empty() && (!carry_compatible(c, fp, sc, cull) || c->carry_blocks != c->render_blocks)) {
-        if (carry_flush(c) != VRT_OK) return VRT_E_DEVICE;
-    }
-    if (!c->d_carry_state || c->carry_blocks != c->render_blocks) {   // (the pools are empty here)
-        HIP_TRY(sync_guarded(c, c->carry_stream));
-        if (c->d_carry_state) { HIP_TRY(hipFree(c->d_carry_state)); c->d_carry_state = nullptr; }
-        if (dalloc(&c->d_carry_state, pool_carry_bytes(c->cfg.grid_res, c->render_blocks) / sizeof(uint32_t)) != hipSuccess) { c->d_carry_state = nullptr; return fail(VRT_E_DEVICE, "no memory for the carried pools"); }
-        c->carry_blocks = c->render_blocks;
-    }
-    if (c->main_dirty) {  // uploads / prepare / sky kernels / passes of the other schedule queued on the main stream come first
-        HIP_TRY(hipEventRecord(c->ev_main, c->stream));
-        HIP_TRY(hipStreamWaitEvent(c->carry_stream, c->ev_main, 0));
-        c->main_dirty = false;
-    }
-    const int set = (int)(c->carry_seq % VRT_CARRY_SETS);
-    // this set was last read by the pass one launch younger than the one that wrote it (as its "previous" g-buffer)
-    const int reader = (set + 1) % VRT_CARRY_SETS;
-    if (c->ev_ct_valid[reader]) HIP_TRY(hipStreamWaitEvent(c->carry_stream, c->ev_ct[reader], 0));
-    if (c->ev_ct_valid[set]) HIP_TRY(hipStreamWaitEvent(c->carry_stream, c->ev_ct[set], 0));
-    if (c->pending.size() > 192) resolve_events(c);
-    hipEvent_t a, b;
-    if (record(c, 0, &a, &b) != VRT_OK) return VRT_E_DEVICE;
-    HIP_TRY(hipEventRecord(a, c->carry_stream));
-    const unsigned seq = c->launch_seq++;
-    if (c->test_fail_launch >= 0 && (unsigned)c->test_fail_launch == seq) return fail(VRT_E_DEVICE, "injected launch failure (VRT_TEST_FAIL_LAUNCH)");
-    HIP_TRY(launch_render_pool_carry(c->carry_stream, c->cfg.grid_res, c->render_blocks, fp, sc, carry_out(c), c->d_work, seq, g, c->d_pool_scratch,
-                                     g > 1 ? c->d_carry_prim : nullptr, cull, c->d_carry_state, (int)c->npix, (int)(c->npix * VRT_MAX_FUSED),
-                                     VRT_CARRY_SETS, set, false, getenv("VRT_CARRY_FINISH_ALL") != nullptr));   // (A/B: every launch ends its own paths)
-    HIP_TRY(hipEventRecord(b, c->carry_stream));
-    HIP_TRY(hipEventRecord(c->ev_cr[set], c->carry_stream));
-    c->carry_fp = fp; c->carry_sc = sc; c->carry_cull = cull;
-    PendingPass pp;
-    pp.fp = fp; pp.set = set; pp.g = g; pp.last_of_call = last_of_call;
-    pp.prev_normal = c->last_gb_normal; pp.prev_depth = c->last_gb_depth;
-    pp.prev_view = c->prev_view; pp.prev_proj = c->prev_proj;
-    c->carry_pending.push_back(pp);
-    c->last_gb_normal = c->cs_gb_normal + (size_t)set * c->npix;
-    c->last_gb_depth = c->cs_gb_depth + (size_t)set * c->npix;
-    c->canon_in_carry = true; c->carry_last_set = set; c->carry_last_g = g;
-    c->carry_seq++;
-    // the pass of the launch VRT_CARRY_LAG back: its last paths ended in this launch
-    if (c->carry_pending.size() > VRT_CARRY_LAG) {
-        const PendingPass old = c->carry_pending.front();
-        c->carry_pending.pop_front();
-        if (emit_pass(c, old, c->ev_cr[set]) != VRT_OK) return VRT_E_DEVICE;
-    }
-    c->frame += (uint32_t)g;
-    c->stats.path_samples += (uint64_t)g * (uint64_t)c->cfg.width * (uint64_t)(c->own1 - c->own0);
     return VRT_OK;
 }
 
@@ -892,8 +695,6 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
 static int accumulate_impl(vrt_ctx* c, int n_samples) {
     const bool restir = c->cfg.use_restir != 0, instr = c->instrumented;
     if (c->render_blocks == 0) {
-        FLUSH_TRY(c);   // (the grid and the scratch lines the carried paths live in are about to change)
-        if (c->carry_stream) HIP_TRY(sync_guarded(c, c->carry_stream));
         // Two schedules of the same per-path code: the fused one (a lane owns a path, vrt_path.h) and the pooled one
         // (a wave owns a pool of paths in LDS and works stage by stage, vrt_pool.h).  The pooled kernel packs pixel
         // coordinates in 12 bits and the depth in 4, so contexts outside that use the fused one (ReSTIR runs on either:
@@ -945,41 +746,25 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
     // passes run beside them (ensure_overlap: how deep).  Results are unchanged; VRT_OVERLAP=0 turns it off.
     bool may_overlap = c->pooled && can_fuse && !restir;
     if (const char* e = getenv("VRT_OVERLAP")) { if (atoi(e) == 0) may_overlap = false; }
-    // The same launches on the carried schedule (accumulate_carry) unless VRT_PIPE=overlap asks for the overlapped pipeline;
-    // launches that count work finish their own paths (the counters are compared per call).
-    bool carry = may_overlap && !instr;
-    if (const char* e = getenv("VRT_PIPE")) {
-        if (strcmp(e, "overlap") == 0) carry = false;
-        else if (strcmp(e, "carry") != 0) return fail(VRT_E_INVALID, "VRT_PIPE must be 'carry' or 'overlap'");
-    }
     for (int done = 0; done < n_samples;) {
         int g = (can_fuse && n_samples - done > 1) ? (n_samples - done < max_fused ? n_samples - done : max_fused) : 1;
-        if (carry && ensure_carry(c)) {
-            if (accumulate_carry(c, g, done + g >= n_samples) != VRT_OK) return VRT_E_DEVICE;
-            done += g;
-            continue;
+        // One-sample launches are pipelined like fused ones (the reference's own loop is one sample per call: scene.py:177,
+        // 255-256): they render into plane 0 of the rotating copies instead of the HDR buffer.  VRT_OVERLAP_SINGLE=0: only fused ones.
+        bool want_overlap = may_overlap;
+        if (g == 1) { if (const char* e = getenv("VRT_OVERLAP_SINGLE")) { if (atoi(e) == 0) want_overlap = false; } }
+        if ((g > 1 || want_overlap) && !c->d_multi_d) {
+            if (dalloc(&c->d_multi_d, c->npix * VRT_MAX_FUSED) != hipSuccess) { (void)hipGetLastError(); c->d_multi_d = nullptr; g = 1; want_overlap = false; }  // no memory: one launch per sample
         }
-        // the other schedules finish their paths inside the launch: first whatever the carried one left in the pools ...
-        if (carry_flush(c) != VRT_OK) return VRT_E_DEVICE;
-        if (c->canon_in_carry) {
-            // ... and whoever reads pixels this launch does not write (moving camera at half render scale) expects the last
-            // sample of the last launch in the canonical buffers
-            const size_t n = c->npix, set = (size_t)c->carry_last_set, pl = (size_t)(c->carry_last_g - 1);
-            HIP_TRY(hipMemcpyAsync(c->d_color_s, c->cs_color_s + (set * VRT_MAX_FUSED + pl) * n, n * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(c->d_gb_refl, c->cs_refl + (set * VRT_MAX_FUSED + pl) * n, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(c->d_gb_pos, c->cs_gb_pos + set * n, n * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(c->d_gb_mat, c->cs_gb_mat + set * n, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-            c->canon_in_carry = false;
-            c->last_set = 0;
-            c->main_dirty = true;
-        }
-        if (g > 1 && !c->d_multi_d) {
-            if (dalloc(&c->d_multi_d, c->npix * VRT_MAX_FUSED) != hipSuccess) { (void)hipGetLastError(); c->d_multi_d = nullptr; g = 1; }  // no memory: one launch per sample
-        }
-        const bool overlapped = may_overlap && g > 1 && ensure_overlap(c);
+        const bool overlapped = want_overlap && ensure_overlap(c);
+        const bool planes = g > 1 || overlapped;   // the launch writes colour planes of its own, not the HDR buffer
         const int set = overlapped ? (int)(c->pipe_seq % (unsigned)(c->n_streams + 1)) : 0;
         const int lane_of = (int)(c->pipe_seq % (unsigned)c->n_streams);  // which render stream (and pool scratch): consecutive launches take turns
         hipStream_t rs = overlapped ? c->rstream[lane_of] : c->stream;
+        // A launch of half the slots only pays with other launches beside it: one that finds the pipeline empty (the caller
+        // fetches every frame, or this is the first of a run) takes every slot like a launch that is not overlapped.
+        bool lone = !overlapped;
+        if (overlapped && c->grid_div > 1) lone = c->last_render_set < 0 || hipEventQuery(c->ev_r[c->last_render_set]) == hipSuccess;
+        (void)hipGetLastError();   // (hipErrorNotReady is the expected answer)
         if (overlapped) {
             if (c->main_dirty) {  // uploads / prepare / sky kernels queued on the main stream come first
                 HIP_TRY(hipEventRecord(c->ev_main, c->stream));
@@ -989,8 +774,10 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             if (c->ev_t_valid[set]) HIP_TRY(hipStreamWaitEvent(rs, c->ev_t[set], 0));  // the pass that last read this copy
             // dispatch when the launch whose workgroup slots this one will take starts to drain: the one before it, or with
             // launches of half the slots the one before that (the signal carries the number + 1 of the latest launch draining)
-            if (c->drain_signal && c->drain_signalled && c->launch_seq + 1u > (unsigned)c->grid_div)
-                HIP_TRY(hipStreamWaitValue32(rs, c->drain_signal, c->launch_seq + 1u - (unsigned)c->grid_div, hipStreamWaitValueGte, 0xFFFFFFFFu));
+            // -- unless the one before it took EVERY slot (a lone launch): then that one has to drain first
+            const unsigned back = c->prev_launch_full ? 1u : (unsigned)c->grid_div;
+            if (c->drain_signal && c->drain_signalled && c->launch_seq + 1u > back)
+                HIP_TRY(hipStreamWaitValue32(rs, c->drain_signal, c->launch_seq + 1u - back, hipStreamWaitValueGte, 0xFFFFFFFFu));
         } else if (c->last_set != 0) {
             // back to the single copy: whoever reads pixels this launch does not write (moving camera at half render
             // scale) expects the last sample of the last launch in the canonical buffers
@@ -1003,9 +790,8 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             c->last_set = 0;
         }
         if (c->pending.size() > 192) resolve_events(c);
-        // (an asynchronous fetch may still be reading one of the HDR buffers this iteration writes: the render target of a
-        // one-sample launch, the target of each pass)
-        if (wait_cbuf_readers(c, 0) != VRT_OK || wait_cbuf_readers(c, 1) != VRT_OK) return VRT_E_DEVICE;
+        // (an asynchronous fetch may still be reading the HDR buffer this launch renders into; the passes below check theirs)
+        if (!planes && wait_cbuf_readers(c, c->cidx) != VRT_OK) return VRT_E_DEVICE;
         FrameParams fp = make_frame_params(c);
         SceneData sc = make_scene_data(c);
         PixelBuffers out;
@@ -1014,7 +800,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         // reference knows (color_buffer_specular, gbuff_depth_reflection); a fused launch ends on it, so whatever
         // later reads stale pixels (moving camera at half render scale) finds the last sample there, as in the reference
         const size_t last_plane = (size_t)(VRT_MAX_FUSED - 1) * c->npix;
-        out.color_d = g > 1 ? (set ? c->alt_multi_d[set - 1] : c->d_multi_d) : rt;
+        out.color_d = planes ? (set ? c->alt_multi_d[set - 1] : c->d_multi_d) : rt;
         out.color_s = (set ? c->alt_spec_planes[set - 1] + last_plane : c->d_color_s) - (size_t)(g - 1) * c->npix;
         out.gb_refl_depth = (set ? c->alt_refl_planes[set - 1] + last_plane : c->d_gb_refl) - (size_t)(g - 1) * c->npix;
         out.sample_stride = g > 1 ? (int)c->npix : 0;
@@ -1039,15 +825,11 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             if (!c->d_prim_cache[which] && dalloc(&c->d_prim_cache[which], c->npix) != hipSuccess) { (void)hipGetLastError(); c->d_prim_cache[which] = nullptr; }
             prim = c->d_prim_cache[which];
         }
-        // A launch of half the slots only pays with other launches beside it: one that finds the pipeline empty (the caller
-        // fetches every frame, or this is the first of a run) takes every slot like a launch that is not overlapped.
-        bool lone = !overlapped;
-        if (overlapped && c->grid_div > 1) lone = c->last_render_set < 0 || hipEventQuery(c->ev_r[c->last_render_set]) == hipSuccess;
-        (void)hipGetLastError();   // (hipErrorNotReady is the expected answer)
         const int blocks = lone ? c->render_blocks : (c->render_blocks / c->grid_div + 7) & ~7;  // whole rounds of the 8 XCDs
         if (c->pooled) HIP_TRY(launch_render_pool(rs, c->cfg.grid_res, restir, instr, blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch[lane_of - 1] : c->d_pool_scratch, c->drain_signal, prim, culling(c)));
         else HIP_TRY(launch_render(rs, c->cfg.grid_res, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g));
         c->drain_signalled = c->pooled && c->drain_signal != nullptr;
+        c->prev_launch_full = blocks == c->render_blocks;
         HIP_TRY(hipEventRecord(b, rs));
         if (overlapped) {
             HIP_TRY(hipEventRecord(c->ev_r[set], rs));
@@ -1091,6 +873,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             tb.prev_view = c->prev_view; tb.prev_proj = c->prev_proj;
             tb.tile = (done + g >= n_samples && s == passes - 1) ? next_hdr_target(c) : nullptr;   // the pass that completes the call
             tb.tile_row0 = c->own0;
+            if (wait_cbuf_readers(c, ci ^ 1) != VRT_OK) return VRT_E_DEVICE;
             if (record(c, 1, &a, &b) != VRT_OK) return VRT_E_DEVICE;
             HIP_TRY(hipEventRecord(a, c->stream));
             HIP_TRY(launch_temporal(c->stream, fps, tb, c->own0, c->own1, restir ? 1 : g));
@@ -1120,7 +903,6 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
 int vrt_reset(vrt_ctx* c) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     for (int s = 0; s < 2; s++) {
         HIP_TRY(hipMemsetAsync(c->d_hist_d[s], 0, c->npix * sizeof(f4), c->stream));
         HIP_TRY(hipMemsetAsync(c->d_hist_s[s], 0, c->npix * sizeof(f4), c->stream));
@@ -1137,7 +919,6 @@ int vrt_end_frame(vrt_ctx* c) {
 int vrt_sync(vrt_ctx* c) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     HIP_TRY(sync_guarded(c, c->stream));  // every render launch on the render streams has its temporal pass here
     return VRT_OK;
 }
@@ -1156,13 +937,11 @@ static int fetch_rows(vrt_ctx* c, const void* dbuf, size_t elem, void* out) {
 int vrt_fetch_hdr(vrt_ctx* c, float* out) {
     if (!c || !out) return fail(VRT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     return fetch_rows(c, c->d_cbuf[c->cidx], sizeof(f3), out);
 }
 int vrt_fetch_hdr_device(vrt_ctx* c, void* device_ptr) {
     if (!c || !device_ptr) return fail(VRT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     const size_t W = c->cfg.width;
     const char* src = (const char*)c->d_cbuf[c->cidx] + (size_t)(c->own0 - c->buf0) * W * sizeof(f3);
     HIP_TRY(hipMemcpyAsync(device_ptr, src, (size_t)(c->own1 - c->own0) * W * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
@@ -1172,7 +951,6 @@ int vrt_fetch_hdr_device(vrt_ctx* c, void* device_ptr) {
 int vrt_fetch_hdr_device_async(vrt_ctx* c, void* device_ptr) {
     if (!c || !device_ptr) return fail(VRT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     const size_t W = c->cfg.width;
     const char* src = (const char*)c->d_cbuf[c->cidx] + (size_t)(c->own0 - c->buf0) * W * sizeof(f3);
     HIP_TRY(hipMemcpyAsync(device_ptr, src, (size_t)(c->own1 - c->own0) * W * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
@@ -1181,7 +959,6 @@ int vrt_fetch_hdr_device_async(vrt_ctx* c, void* device_ptr) {
 int vrt_set_stream(vrt_ctx* c, void* hip_stream) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     HIP_TRY(sync_guarded(c, c->stream));
     resolve_events(c);
     for (int s = 0; s < VRT_MAX_SETS; s++) c->ev_t_valid[s] = false;  // everything recorded on the old stream has completed
@@ -1195,7 +972,6 @@ int vrt_fetch_ldr(vrt_ctx* c, float* out) {
     if (!c || !out) return fail(VRT_E_INVALID, "null argument");
     if (!c->have_cam) return fail(VRT_E_STATE, "vrt_set_camera has not been called");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     if (c->ev_fetch_src) {   // asynchronous fetches share d_ldr: theirs first
         HIP_TRY(hipEventRecord(c->ev_fetch_src, c->fetch_stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_fetch_src, 0));
@@ -1224,7 +1000,6 @@ static int fetch_async(vrt_ctx* c, void* out, int slot, bool ldr) {
     if (!c || !out || slot < 0 || slot >= VRT_FETCH_SLOTS) return fail(VRT_E_INVALID, "bad argument (slot must be 0..3)");
     if (ldr && !c->have_cam) return fail(VRT_E_STATE, "vrt_set_camera has not been called");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);   // the frame is the one after every accumulate queued so far
     if (ensure_fetch_stream(c) != VRT_OK) return VRT_E_DEVICE;
     const size_t W = c->cfg.width, rows = (size_t)(c->own1 - c->own0), off = (size_t)(c->own0 - c->buf0) * W;
     const int b = c->cidx;
@@ -1275,16 +1050,15 @@ int vrt_host_free(vrt_ctx* c, void* p) {
     HIP_TRY(hipHostFree(p));
     return VRT_OK;
 }
-// The tile a multi-GPU rank hands to the gather, written by the temporal pass itself: the last pass of every vrt_accumulate
-// call also stores its HDR rows [row_begin, row_end) in device_ptrs[k % n], k = the number of such tiles written so far.
-// On the carried schedule the pass of a call is queued up to VRT_CARRY_LAG calls later (or at the next synchronisation):
-// vrt_hdr_targets_written says how many tiles have been QUEUED on the context's stream -- work the caller queues on that
-// stream afterwards (an event for the gather's stream) is ordered behind them.  The caller keeps a tile untouched until
-// its gather has read it: n > VRT_CARRY_LAG + the gathers it keeps in flight.  n = 0 ends it.
+// The tile a multi-GPU rank hands to the gather, written by the temporal pass itself (12 bytes more per pixel of a pass that
+// moves ~110) instead of a device-to-device copy behind it: the last pass of every vrt_accumulate call also stores its HDR
+// rows [row_begin, row_end) in device_ptrs[k % n], k = the number of such tiles written so far (vrt_hdr_targets_written);
+// the pass is queued on the context's stream by the call itself, so work the caller queues on that stream afterwards (an
+// event for the gather's stream) is ordered behind the tile.  The caller keeps a tile untouched until its gather has read
+// it.  n = 0 ends it.
 int vrt_set_hdr_targets(vrt_ctx* c, void* const* device_ptrs, int n) {
     if (!c || n < 0 || (n > 0 && !device_ptrs)) return fail(VRT_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     c->hdr_targets.assign(device_ptrs, device_ptrs + n);
     c->hdr_targets_written = 0;
     return VRT_OK;
@@ -1297,10 +1071,9 @@ int vrt_hdr_targets_written(vrt_ctx* c, uint64_t* count) {
 int vrt_fetch_buffer(vrt_ctx* c, int which, void* out) {
     if (!c || !out) return fail(VRT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     // the g-buffer written by the most recent accumulate (whichever schedule rendered it)
-    const f3* pos = c->canon_in_carry ? c->cs_gb_pos + (size_t)c->carry_last_set * c->npix : (c->last_set ? c->alt_gb_pos[c->last_set - 1] : c->d_gb_pos);
-    const uint32_t* gmat = c->canon_in_carry ? c->cs_gb_mat + (size_t)c->carry_last_set * c->npix : (c->last_set ? c->alt_gb_mat[c->last_set - 1] : c->d_gb_mat);
+    const f3* pos = c->last_set ? c->alt_gb_pos[c->last_set - 1] : c->d_gb_pos;
+    const uint32_t* gmat = c->last_set ? c->alt_gb_mat[c->last_set - 1] : c->d_gb_mat;
     switch (which) {
         case VRT_BUF_GBUF_DEPTH: return fetch_rows(c, c->last_gb_depth, 4, out);
         case VRT_BUF_GBUF_NORMAL: return fetch_rows(c, c->last_gb_normal, 4, out);
@@ -1330,23 +1103,20 @@ int vrt_fetch_buffer(vrt_ctx* c, int which, void* out) {
 int vrt_get_stats(vrt_ctx* c, vrt_stats* out) {
     if (!c || !out) return fail(VRT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     HIP_TRY(sync_guarded(c, c->stream));
     resolve_events(c);
     Counters h;
     HIP_TRY(hipMemcpy(&h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     c->stats.rays = h.rays; c->stats.dda_iters = h.iters; c->stats.occupancy_queries = h.queries;
     c->stats.closest_hits = h.closest_hits; c->stats.sky_lookups = h.sky_lookups;
-    c->stats.pipeline_flags = (c->carry_ready && c->carry_seq > 0 ? 0x80000000u : 0u) |
-                              (c->overlap_ready ? 1u : 0u) | (c->drain_signal ? 2u : 0u) | (((uint32_t)c->gate_releases << 8) & 0x7fffff00u) |
-                              (c->overlap_ready ? ((uint32_t)c->n_streams << 2) | ((uint32_t)c->grid_div << 5) : 0u);
+    c->stats.pipeline_flags = (c->overlap_ready ? 1u : 0u) | (c->drain_signal ? 2u : 0u) | ((uint32_t)c->gate_releases << 8) |
+                              (c->overlap_ready ? ((uint32_t)(c->n_streams >> 1) << 2) | ((uint32_t)c->grid_div << 5) : 0u);
     *out = c->stats;
     return VRT_OK;
 }
 int vrt_reset_stats(vrt_ctx* c) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    FLUSH_TRY(c);
     HIP_TRY(sync_guarded(c, c->stream));
     resolve_events(c);
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), c->stream));   // on the stream the counting launches follow on

@@ -49,15 +49,6 @@ hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool in
                               uint32_t* drain_signal,   // signal memory (or null): receives launch_seq + 1 when the launch starts to drain
                               PrimaryRecord* prim_cache,        // per-pixel camera-ray records shared by the fused samples (or null), npix entries
                               bool cull);                       // the instantiation that tests rays against sc.cull (cull_ray, vrt_trace.h)
-// The pooled schedule with paths carried from launch to launch (CarryArgs, vrt_kernels.hip; ReSTIR off, not instrumented):
-// consecutive launches on ONE stream with the same grid; `carry_state` holds pool_carry_bytes() bytes, zeroed before the first
-// launch; the per-set output arrays are `gb_stride` / `plane_stride` elements apart and `out` points at set 0; flush = a launch
-// without new work that runs every carried path to its end.
-size_t pool_carry_bytes(int grid_res, int n_blocks);
-hipError_t launch_render_pool_carry(hipStream_t st, int grid_res, int n_blocks, const FrameParams& fp, const SceneData& sc, const PixelBuffers& out,
-                                    unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold, PrimaryRecord* prim_cache, bool cull,
-                                    uint32_t* carry_state, int gb_stride, int plane_stride, int n_sets, int cur_set, bool flush,
-                                    bool finish_all /* diagnostic: a launch with work that carries nothing out either */);
 hipError_t launch_mat_derived(hipStream_t st, const float* mats, float* mats_x /*[128][8]*/);  // after every material upload
 // spatial reuse over rows [r0, r1); first a per-pixel prepare pass over all rows the launch holds (fp.row0..fp.row1) into gb.geo / gb.src
 hipError_t launch_gris(hipStream_t st, int grid_res, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1);

@@ -317,32 +317,14 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-// Paths carried across launches (CARRY): see CarryRef (vrt_pool.h) and CarryArgs below.
-struct CarryArgs {
-    uint32_t* state;      // per wave of the grid: VRT_POOL_WORDS * 64 state words, then the pool's PF_COUNT * VRT_POOL_SLOTS dwords
-    int gb_stride;        // elements between the sets of the g-buffer arrays / of the plane arrays
-    int plane_stride;
-    int n_sets;
-    int cur_set;          // set of THIS launch's paths
-    uint32_t cur_tag;     // launch number & 3
-    int drain_all;        // 1: nothing may be carried out of this launch (the flush before a synchronisation)
-    unsigned* announce;       // raised by the first wave that finds the launch's work used up, polled by the others: a word on a
-    unsigned* next_announce;  // line of its own (2048 waves reading the line of a work head slow its atomics down fourfold)
-};
-#ifndef VRT_CARRY_POLL
-#define VRT_CARRY_POLL 2   // 0: a wave learns that the work is used up from its own BEGIN only; 1: it looks at `announce` at every census;
-                           // 2: only once its own work range is used up (the ranges end together: that is the end of the launch)
-#endif
-#define VRT_CARRY_WAVE_WORDS (VRT_POOL_WORDS * 64 + PF_COUNT * VRT_POOL_SLOTS)
-
-template <int G, bool RESTIR, bool INSTR, bool BLACK_SUN, bool CULL, bool CARRY = false>
+template <int G, bool RESTIR, bool INSTR, bool BLACK_SUN, bool CULL>
 // 208 registers per wave (the attribute counts half of the unified file): two waves per SIMD then leave the 96 that
 // k_temporal runs in beside them (see there).  The allocator would take 238; the cap costs 28 bytes of scratch.
 // The ReSTIR instantiation (no overlapped launches, so nothing runs beside it) takes the two-wave maximum of 256.
 #ifndef VRT_POOL_HALF_VGPRS
 #define VRT_POOL_HALF_VGPRS 104
 #endif
-__device__ __forceinline__ void render_pool_body(const FrameParams& fp, const SceneData& sc, const PixelBuffers& out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache, const CarryArgs ca = CarryArgs{nullptr, 0, 0, 1, 0, 0u, 0, nullptr, nullptr}) {
+__device__ __forceinline__ void render_pool_body(const FrameParams& fp, const SceneData& sc, const PixelBuffers& out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
     constexpr int WAVES = PoolGeom<G>::waves;
     constexpr bool BIG = (G == 256);   // which coarse levels are staged how: see LdsPyramid2
     __shared__ ulonglong2 s_l12[BIG ? 1 : 512];
@@ -352,7 +334,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
     __shared__ uint32_t s_fine_base[BIG ? 1 : 512];
     __shared__ float s_mats[128 * 14];
     __shared__ float s_cull[8];
-    __shared__ __attribute__((aligned(16))) uint32_t s_pool[WAVES][PF_COUNT * VRT_POOL_SLOTS];
+    __shared__ uint32_t s_pool[WAVES][PF_COUNT * VRT_POOL_SLOTS];
     __shared__ uint32_t s_state[WAVES][VRT_POOL_WORDS * 64];
     __shared__ uint32_t s_list[WAVES][VRT_POOL_SLOTS];
     LdsPyramid2<G, CULL> P;
@@ -380,29 +362,11 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
     if (threadIdx.x < 8) s_cull[threadIdx.x] = sc.cull[threadIdx.x];
     if (blockIdx.x == 0 && threadIdx.x < VRT_WORK_HEADS) next_counter[threadIdx.x * VRT_WORK_HEAD_STRIDE] = 0u;  // the next launch's heads (idle during this launch)
     if (blockIdx.x == 0 && threadIdx.x == 0) next_counter[1] = 0u;  // and its "drain announced" word
-    if constexpr (CARRY) { if (blockIdx.x == 0 && threadIdx.x == 0) *ca.next_announce = 0u; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* const pool = s_pool[wave];
     uint32_t* const state = s_state[wave];
     uint32_t* const list = s_list[wave];
-    // a slot's state word: stage in the low four bits, the tag of the launch its path was begun in above them (0 without CARRY)
-    uint32_t* carry_wave = nullptr;
-    if constexpr (CARRY) {
-        // the paths the wave in this place of the last launch left behind: states first, the pool only if one of them is live
-        carry_wave = ca.state + (size_t)(blockIdx.x * WAVES + wave) * VRT_CARRY_WAVE_WORDS;
-        bool live = false;
-        for (int k = 0; k < VRT_POOL_WORDS; k++) {
-            const uint32_t v = (k * 64 + lane < VRT_POOL_SLOTS) ? carry_wave[k * 64 + lane] : 4u;
-            state[k * 64 + lane] = v;
-            live = live || ((v & 15u) != (uint32_t)SLOT_EMPTY && (v & 15u) != 4u);
-        }
-        if (__ballot(live) != 0ULL) {
-            const uint4* src = (const uint4*)(carry_wave + VRT_POOL_WORDS * 64);
-            for (int i = lane; i < PF_COUNT * VRT_POOL_SLOTS / 4; i += 64) ((uint4*)pool)[i] = src[i];
-        }
-    } else {
-        for (int k = 0; k < VRT_POOL_WORDS; k++) state[k * 64 + lane] = (k * 64 + lane < VRT_POOL_SLOTS) ? (uint32_t)SLOT_EMPTY : 4u;
-    }
+    for (int k = 0; k < VRT_POOL_WORDS; k++) state[k * 64 + lane] = (k * 64 + lane < VRT_POOL_SLOTS) ? (uint32_t)SLOT_EMPTY : 4u;
     __syncthreads();
     SceneData scl = sc;
     scl.mats = s_mats;
@@ -415,8 +379,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
     const unsigned total = (unsigned)(tiles_x * tiles_y) * 64u * (unsigned)n_samples;  // (tile, sample, pixel-in-tile) items
     TraceStats ts;
     stats_zero(ts);
-    bool exhausted = CARRY && total == 0u;  // wave-uniform (a launch without items: the flush of the carried paths)
-    const uint32_t must_tag = (ca.cur_tag + 1u) & 3u;  // CARRY: paths begun three launches ago end in this one (their tag comes round next)
+    bool exhausted = false;  // wave-uniform
     // items are split into VRT_WORK_HEADS contiguous ranges of whole tiles; this wave starts on its XCD's range
     // a range is a whole number of tiles with all their samples; inside it items run sample-major (all tiles' sample 0,
     // then all tiles' sample 1, ...) so that the camera-ray records of sample 0 are there when the others begin
@@ -453,23 +416,11 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
         // census
         uint32_t st[VRT_POOL_WORDS];
         int cnt[4] = {0, 0, 0, 0};
-        uint32_t announced = 0u;
-        if constexpr (CARRY && VRT_CARRY_POLL != 0) {  // another wave found the work used up
-            if (!exhausted && (VRT_CARRY_POLL == 1 || heads_left < (int)VRT_WORK_HEADS)) announced = __builtin_nontemporal_load(ca.announce);
-        }
-        bool must = false;   // CARRY: a path of mine that may not be carried out of this launch
 #pragma unroll
         for (int k = 0; k < VRT_POOL_WORDS; k++) {
             st[k] = state[k * 64 + lane];
 #pragma unroll
-            for (int q = 0; q < 4; q++) cnt[q] += __popcll(__ballot((st[k] & 15u) == (uint32_t)q));
-            if constexpr (CARRY) must = must || ((st[k] & 15u) >= 1u && (st[k] & 15u) <= 3u && (ca.drain_all != 0 || (st[k] >> 4) == must_tag));
-        }
-        if constexpr (CARRY) {
-            if (__builtin_amdgcn_readfirstlane((int)announced) != 0) exhausted = true;
-            // the launch's work is handed out: leave with whatever is in the pool (the next launch goes on with it), unless a
-            // path is among it that has to end in this launch
-            if (exhausted && __ballot(must) == 0ULL) break;
+            for (int q = 0; q < 4; q++) cnt[q] += __popcll(__ballot(st[k] == (uint32_t)q));
         }
         if (exhausted) cnt[SLOT_EMPTY] = 0;
         // the stage with the most slots waiting; ties: SHADE, ESCAPE, WALK, BEGIN.  (Rules that hold WALK back until
@@ -483,9 +434,9 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
         int n = 0;
 #pragma unroll
         for (int k = 0; k < VRT_POOL_WORDS; k++) {
-            const bool mine = (st[k] & 15u) == (uint32_t)stage;
+            const bool mine = st[k] == (uint32_t)stage;
             const unsigned long long m = __ballot(mine);
-            if (mine) list[n + lane_rank(m)] = (uint32_t)(k * 64 + lane) | ((st[k] >> 4) << 8);   // slot | tag << 8
+            if (mine) list[n + lane_rank(m)] = (uint32_t)(k * 64 + lane);
             n += __popcll(m);
         }
         wave_lds_sync();
@@ -507,7 +458,6 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
             SlotRef s;
             s.base = pool; s.stride = VRT_POOL_SLOTS;
             int slot = 0, iters0 = 0;
-            uint32_t slot_tag = 0u;
             for (;;) {
                 // event: finished walks go to their slots, idle lanes take the next pending rays -- or, with the
                 // list empty and few walks left, the rest is suspended
@@ -516,10 +466,10 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
                 if (ended) {
                     VRT_REGION(16);
                     walk_store(s, w);
-                    state[slot] = (uint32_t)slot_state_after_walk<G>(w.t, s.f(PF_FLOOR_T)) | (slot_tag << 4);
+                    state[slot] = (uint32_t)slot_state_after_walk<G>(w.t, s.f(PF_FLOOR_T));
                     if (prim_cache) {  // the camera ray of a pixel's sample 0: leave its record for the other samples
                         const uint32_t ids = s.u(PF_IDS);
-                        if ((ids >> 24) == (ca.cur_tag << 6))  // depth 0, sample 0, begun in this launch (the check word tells a reader whether it saw all of the record)
+                        if ((ids >> 24) == 0u)  // depth 0, sample 0 (the check word tells a reader whether it saw all of the record)
                             primary_record_store(&prim_cache[((int)((ids >> 12) & 0xfffu) - fp.row0) * fp.W + (int)(ids & 0xfffu)], primary_record(s, prim_tag));
                     }
                     ts.iters += (unsigned)(w.iters - iters0);
@@ -538,9 +488,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
                     const int idx = head + lane_rank(idle);
                     if (!active && idx < n) {
                         VRT_REGION(15);
-                        const uint32_t e = list[idx];
-                        slot = (int)(e & 0xffu);
-                        slot_tag = e >> 8;
+                        slot = (int)list[idx];
                         s.base = pool + slot;
                         walk_load<G>(s, w);
                         coarse_fetch(P, w.ix, w.iy, w.iz, cw);
@@ -583,8 +531,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
                         exhausted = true;
                         // the launch starts to drain: tell the stream holding the NEXT launch back until now (vrt_api.hip)
                         // (the first wave to get here does; word 1 of this launch's head line says whether one has)
-                        if constexpr (CARRY) { if (lane == 0) __hip_atomic_store(ca.announce, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                        else if (drain_signal && lane == 0 && atomicExch(work_counter + 1, 1u) == 0u)
+                        if (drain_signal && lane == 0 && atomicExch(work_counter + 1, 1u) == 0u)
                             __hip_atomic_fetch_max(drain_signal, drain_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
                 }
@@ -594,34 +541,21 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
             if (lane < take) {
                 SlotRef s;
                 s.stride = VRT_POOL_SLOTS;
-                const uint32_t e = list[lane];
-                CarryRef cr = CarryRef{0u, 0, 0};
-                if constexpr (CARRY) {
-                    if (stage != SLOT_EMPTY) {  // the output set of the launch the path was begun in
-                        cr.tag = e >> 8;
-                        int set = ca.cur_set - (int)((ca.cur_tag - cr.tag) & 3u);
-                        if (set < 0) set += ca.n_sets;
-                        cr.gb_off = set * ca.gb_stride;
-                        cr.plane_off = set * ca.plane_stride;
-                    }
-                }
                 if (stage == SLOT_SHADE) {
                     VRT_REGION(11);
-                    const int slot = (int)(e & 0xffu);
+                    const int slot = (int)list[lane];
                     s.base = pool + slot;
-                    const uint32_t nst = (uint32_t)pool_shade<HIT_SOMETHING, BLACK_SUN, RESTIR>(fp, scl, P, out, s, cold_wave + slot * COLD, ts, cr);
-                    state[slot] = nst == (uint32_t)SLOT_EMPTY ? nst : (nst | (cr.tag << 4));
+                    state[slot] = (uint32_t)pool_shade<HIT_SOMETHING, BLACK_SUN, RESTIR>(fp, scl, P, out, s, cold_wave + slot * COLD, ts);
                 } else if (stage == SLOT_ESCAPE) {
                     VRT_REGION(12);
-                    const int slot = (int)(e & 0xffu);
+                    const int slot = (int)list[lane];
                     s.base = pool + slot;
-                    const uint32_t nst = (uint32_t)pool_shade<HIT_NOTHING, false, RESTIR>(fp, scl, P, out, s, cold_wave + slot * COLD, ts, cr);
-                    state[slot] = nst == (uint32_t)SLOT_EMPTY ? nst : (nst | (cr.tag << 4));
+                    state[slot] = (uint32_t)pool_shade<HIT_NOTHING, false, RESTIR>(fp, scl, P, out, s, cold_wave + slot * COLD, ts);
                 } else {
                     VRT_REGION(13);
                     const unsigned my = base + (unsigned)lane;
                     if (my < limit) {
-                        const int slot = (int)(e & 0xffu);
+                        const int slot = (int)list[lane];
                         s.base = pool + slot;
                         const unsigned j = my - range0;  // sample-major inside the range (n_samples <= 4)
                         const int sample = (int)(j >= per_sample) + (int)(j >= 2u * per_sample) + (int)(j >= 3u * per_sample);
@@ -639,15 +573,14 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
                             }
                             VRT_SUB_CLOCK(1);
                             int st;
-                            if (known) st = pool_begin_known<G>(fp, s, u, v, sample, rec, ca.cur_tag);
+                            if (known) st = pool_begin_known<G>(fp, s, u, v, sample, rec);
                             else {
-                                st = pool_begin<G, CULL>(fp, scl.cull, s, u, v, sample, ts, ca.cur_tag);
+                                st = pool_begin<G, CULL>(fp, scl.cull, s, u, v, sample, ts);
                                 // a camera ray with nothing to walk (it misses the grid or every solid voxel) is finished here: its
                                 // record is left here too
                                 if (prim_cache && sample == 0 && st != SLOT_RAY) primary_record_store(&prim_cache[(v - fp.row0) * fp.W + u], primary_record(s, prim_tag));
                             }
-                            // (a camera ray that was over at once -- sky behind an empty grid -- left a path to finish: it keeps the tag)
-                            state[slot] = (uint32_t)st | (ca.cur_tag << 4);
+                            state[slot] = (uint32_t)st;
                             VRT_SUB_CLOCK(sample > 0 ? 2 : 3);
                         }
                     }
@@ -656,21 +589,6 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
         }
     }
     VRT_POOL_CLOCK(4);
-    if constexpr (CARRY) {  // what is left of the pool goes to the wave in this place of the next launch
-        wave_lds_sync();
-        bool live = false;
-        for (int k = 0; k < VRT_POOL_WORDS; k++) {
-            if (k * 64 + lane < VRT_POOL_SLOTS) {
-                const uint32_t v = state[k * 64 + lane];
-                carry_wave[k * 64 + lane] = v;
-                live = live || ((v & 15u) != (uint32_t)SLOT_EMPTY);
-            }
-        }
-        if (__ballot(live) != 0ULL) {
-            uint4* dst = (uint4*)(carry_wave + VRT_POOL_WORDS * 64);
-            for (int i = lane; i < PF_COUNT * VRT_POOL_SLOTS / 4; i += 64) dst[i] = ((const uint4*)pool)[i];
-        }
-    }
 #if defined(VRT_DIAG_REGIONS)
     if (lane == 0)
         for (int q = 0; q < 6; q++) atomicAdd(&g_vrt_region[2 * (20 + q)], t_stage[q]);
@@ -683,11 +601,6 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
 template <int G, bool INSTR, bool BLACK_SUN, bool CULL>
 __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(VRT_POOL_HALF_VGPRS))) void k_render_pool(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
     render_pool_body<G, false, INSTR, BLACK_SUN, CULL>(fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, drain_value, prim_cache);
-}
-// the same kernel with paths carried from launch to launch (CarryArgs): consecutive launches of one stream, no tail between them
-template <int G, bool BLACK_SUN, bool CULL>
-__global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(VRT_POOL_HALF_VGPRS))) void k_render_pool_carry(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t launch_tag, PrimaryRecord* prim_cache, CarryArgs ca) {
-    render_pool_body<G, false, false, BLACK_SUN, CULL, true>(fp, sc, out, work_counter, next_counter, n_samples, cold, nullptr, launch_tag, prim_cache, ca);
 }
 template <int G, bool INSTR, bool CULL>
 __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(128))) void k_render_pool_restir(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
@@ -901,29 +814,6 @@ hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool in
         else VRT_BY_GRID(grid_res, VRT_BY_2(instr, black_sun, hipLaunchKernelGGL((k_render_pool<G, A, B, false>), VRT_POOL_ARGS)));
     }
 #undef VRT_POOL_ARGS
-    VRT_LAUNCH_CHECK();
-    return hipSuccess;
-}
-size_t pool_carry_bytes(int grid_res, int n_blocks) { return (size_t)n_blocks * pool_waves_per_block(grid_res) * VRT_CARRY_WAVE_WORDS * sizeof(uint32_t); }
-// One launch of the carried schedule.  n_items_samples = 0 (n_samples with fp.row1 == fp.row0 is not needed: pass flush = true)
-// launches the flush: no new work, every carried path runs to its end.
-hipError_t launch_render_pool_carry(hipStream_t st, int grid_res, int n_blocks, const FrameParams& fp, const SceneData& sc, const PixelBuffers& out,
-                                    unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold, PrimaryRecord* prim_cache, bool cull,
-                                    uint32_t* carry_state, int gb_stride, int plane_stride, int n_sets, int cur_set, bool flush, bool finish_all) {
-    unsigned* work_counter = work_counters + (launch_seq & 15u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
-    unsigned* next_counter = work_counters + ((launch_seq + 8u) & 15u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
-    dim3 g(n_blocks), b(64 * pool_waves_per_block(grid_res));
-    const bool black_sun = !((fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f);
-    CarryArgs ca;
-    ca.state = carry_state; ca.gb_stride = gb_stride; ca.plane_stride = plane_stride; ca.n_sets = n_sets; ca.cur_set = cur_set;
-    ca.cur_tag = launch_seq & 3u; ca.drain_all = (flush || finish_all) ? 1 : 0;
-    unsigned* const flags = work_counters + 16u * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);   // behind the sixteen sets of heads: a line per set
-    ca.announce = flags + (launch_seq & 15u) * VRT_WORK_HEAD_STRIDE;
-    ca.next_announce = flags + ((launch_seq + 8u) & 15u) * VRT_WORK_HEAD_STRIDE;
-    FrameParams fpl = fp;
-    if (flush) fpl.row1 = fpl.row0;   // no rows, no items: the kernel sees its work used up from the start
-    // (the index arithmetic of carried paths uses fp.row0 and fp.W only, which the flush keeps)
-    VRT_BY_GRID(grid_res, VRT_BY_2(black_sun, cull, hipLaunchKernelGGL((k_render_pool_carry<G, A, B>), g, b, 0, st, fpl, sc, out, work_counter, next_counter, n_samples, cold, launch_seq + 1u, prim_cache, ca)));
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }

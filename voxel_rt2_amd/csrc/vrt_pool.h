@@ -42,7 +42,7 @@ enum {  // slot states
 
 enum {  // LDS columns of a slot (dwords)
     PF_POS = 0, PF_DIR = 3, PF_THR = 6, PF_CONTRIB = 9, PF_RNG = 12,
-    PF_IDS = 13,      // pix_u | pix_v << 12 | depth << 24 | sample << 28 | launch tag << 30 (carried paths, CarryRef)
+    PF_IDS = 13,      // pix_u | pix_v << 12 | depth << 24 | sample << 28
     PF_FLAGS = 14,    // first_lobe | sky_primary << 2
     PF_REFL = 15,
     PF_FLOOR_T = 16,  // floor_probe() of the pending ray
@@ -107,25 +107,15 @@ VRT_DEV void walk_load(const SlotRef& s, RayWalk& w) {
     w.iters = (int)s.u(PF_ITERS);
 }
 
-VRT_DEV uint32_t pack_ids(int u, int v, int depth, int sample, uint32_t tag = 0u) {
-    return (uint32_t)u | ((uint32_t)v << 12) | ((uint32_t)depth << 24) | ((uint32_t)sample << 28) | (tag << 30);
+VRT_DEV uint32_t pack_ids(int u, int v, int depth, int sample) {
+    return (uint32_t)u | ((uint32_t)v << 12) | ((uint32_t)depth << 24) | ((uint32_t)sample << 28);
 }
 
-// Paths carried from launch to launch (k_render_pool<..., CARRY>, vrt_kernels.hip): a wave that finds the launch's work used
-// up saves its pool and leaves; the wave in the same place of the NEXT launch picks the paths up.  A path keeps writing to
-// the output copy ("set") of the launch it was begun in: `tag` = that launch's number modulo 4 (also kept in the slot's
-// state word and in PF_IDS), the offsets = that set's distance from set 0 in the per-set arrays.  All zero without carrying.
-struct CarryRef {
-    uint32_t tag;
-    int gb_off;      // elements: g-buffer arrays (one plane per set)
-    int plane_off;   // elements: colour / reflection-depth arrays (VRT_MAX_FUSED planes per set)
-};
-
 template <bool RESTIR>
-VRT_DEV void path_store_hot(const SlotRef& s, const Path<RESTIR>& p, uint32_t tag = 0u) {
+VRT_DEV void path_store_hot(const SlotRef& s, const Path<RESTIR>& p) {
     s.sv(PF_POS, p.pos); s.sv(PF_DIR, p.d); s.sv(PF_THR, p.thr); s.sv(PF_CONTRIB, p.contrib);
     s.su(PF_RNG, p.rng.s);
-    s.su(PF_IDS, pack_ids(p.pix_u, p.pix_v, p.depth, p.sample, tag));
+    s.su(PF_IDS, pack_ids(p.pix_u, p.pix_v, p.depth, p.sample));
     s.su(PF_FLAGS, (uint32_t)p.first_lobe | ((uint32_t)p.sky_primary << 2));
     s.sf(PF_REFL, p.refl_dist);
 }
@@ -152,7 +142,7 @@ VRT_DEV void path_load_hot(const SlotRef& s, Path<RESTIR>& p) {
     p.rng.s = s.u(PF_RNG);
     const uint32_t ids = s.u(PF_IDS), fl = s.u(PF_FLAGS);
     p.pix_u = (int)(ids & 0xfffu); p.pix_v = (int)((ids >> 12) & 0xfffu);
-    p.depth = (int)((ids >> 24) & 15u); p.sample = (int)((ids >> 28) & 3u);
+    p.depth = (int)((ids >> 24) & 15u); p.sample = (int)(ids >> 28);
     p.first_lobe = (int)(fl & 3u); p.sky_primary = (int)((fl >> 2) & 1u);
     p.refl_dist = s.f(PF_REFL);
     path_cold_defaults(p);
@@ -265,10 +255,10 @@ VRT_DEV void primary_record_store(PrimaryRecord* at, const PrimaryRecord& r) { *
 VRT_DEV PrimaryRecord primary_record_load(const PrimaryRecord* at) { return *at; }
 #endif
 template <int G>
-VRT_DEV int pool_begin_known(const FrameParams& fp, const SlotRef& s, int u, int v, int sample, const PrimaryRecord& rec, uint32_t tag = 0u) {
+VRT_DEV int pool_begin_known(const FrameParams& fp, const SlotRef& s, int u, int v, int sample, const PrimaryRecord& rec) {
     Path<false> p;
     path_begin_along(fp, p, u, v, sample, mk3(dm_u2f(rec.dx), dm_u2f(rec.dy), dm_u2f(rec.dz)));
-    path_store_hot(s, p, tag);
+    path_store_hot(s, p);
     s.su(PF_FLOOR_T, rec.ft);
     s.su(PF_T, rec.x); s.su(PF_CELL_XY, rec.y); s.su(PF_CELL_Z, rec.z); s.su(PF_ITERS, 0u);
     return slot_state_after_walk<G>(dm_u2f(rec.x), dm_u2f(rec.ft));
@@ -276,10 +266,10 @@ VRT_DEV int pool_begin_known(const FrameParams& fp, const SlotRef& s, int u, int
 
 // BEGIN: work item (u, v, sample) -> camera ray pending.
 template <int G, bool CULL = true>
-VRT_DEV int pool_begin(const FrameParams& fp, const float* cull, const SlotRef& s, int u, int v, int sample, TraceStats& ts, uint32_t tag = 0u) {
+VRT_DEV int pool_begin(const FrameParams& fp, const float* cull, const SlotRef& s, int u, int v, int sample, TraceStats& ts) {
     Path<false> p;
     path_begin(fp, p, u, v, sample);
-    path_store_hot(s, p, tag);
+    path_store_hot(s, p);
     return pool_launch_ray<G, CULL>(fp, cull, s, p.pos, p.d, ts);
 }
 
@@ -287,7 +277,7 @@ VRT_DEV int pool_begin(const FrameParams& fp, const float* cull, const SlotRef& 
 // segment, then either set up the bounce ray or finish the path.  Returns the slot's next state.
 template <int KIND, bool BLACK_SUN, bool RESTIR = false, class PyrT>
 VRT_DEV int pool_shade(const FrameParams& fp, const SceneData& sc, const PyrT& P, const PixelBuffers& out, const SlotRef& s,
-                       uint32_t* cold_line, TraceStats& ts, const CarryRef cr = CarryRef{0u, 0, 0}) {
+                       uint32_t* cold_line, TraceStats& ts) {
     Path<RESTIR> p;
     path_load_hot(s, p);
     const int local_idx = (p.pix_v - fp.row0) * fp.W + p.pix_u;
@@ -304,14 +294,14 @@ VRT_DEV int pool_shade(const FrameParams& fp, const SceneData& sc, const PyrT& P
         hit_voxel<false, PyrT::G>(fp, sc, world_to_voxel<PyrT::G>(p.pos), p.d, tr, h, ts);
     }
     if constexpr (RESTIR) { if (depth > 0) path_load_cold(cold_line, p); }  // the reconnection state is updated at every vertex
-    const bool done = path_shade<RESTIR, KIND, BLACK_SUN>(fp, sc, P, out, local_idx + cr.gb_off, p, h, ts);
+    const bool done = path_shade<RESTIR, KIND, BLACK_SUN>(fp, sc, P, out, local_idx, p, h, ts);
     if (done) {
         if constexpr (!RESTIR) { if (depth > 0) path_load_cold(cold_line, p); }
-        path_finish<RESTIR>(fp, sc, out, local_idx + cr.plane_off, p, ts);
+        path_finish<RESTIR>(fp, sc, out, local_idx, p, ts);
         return SLOT_EMPTY;
     }
     if (RESTIR || depth == 0) path_store_cold(cold_line, p);
-    path_store_hot(s, p, cr.tag);
+    path_store_hot(s, p);
     return pool_launch_ray<PyrT::G, PyrT::cull>(fp, sc.cull, s, p.pos, p.d, ts);
 }
 
