@@ -166,6 +166,9 @@ int vrt_fetch_ldr(vrt_ctx* ctx, float* out);
  * that the copy runs beside the following launches; for a shard only its rows of `out` are written. */
 int vrt_fetch_hdr_async(vrt_ctx* ctx, float* out, int slot);
 int vrt_fetch_ldr_async(vrt_ctx* ctx, float* out, int slot);
+/* the LDR image as rgba8[H][W][4] = u8(clamp(c, 0, 1) * 255 + 0.5): what a display or a PNG takes, a quarter of the bytes
+ * (at 1080p the f32 image is 33 MB a frame, more than the host link carries at a frame per millisecond) */
+int vrt_fetch_ldr8_async(vrt_ctx* ctx, uint8_t* out, int slot);
 int vrt_fetch_wait(vrt_ctx* ctx, int slot);
 /* page-locked host memory for the asynchronous fetches (hipHostMalloc / hipHostFree) */
 int vrt_host_alloc(vrt_ctx* ctx, uint64_t bytes, void** out);

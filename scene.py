@@ -12,7 +12,8 @@ finish() (reference scene.py:171-297, an endless GGUI window loop):
   * the camera stays at the reference's initial pose (scene.py:28-29); no WASD / mouse.
 
 Environment: VRT_RES=WxH (default 1920x1080 = SCREEN_RES), VRT_FRAMES, VRT_SPP, VRT_OUT, VRT_SEED,
-VRT_MAX_DEPTH, VRT_RESTIR, VRT_SKY_RES, VRT_DEVICE.
+VRT_MAX_DEPTH, VRT_RESTIR, VRT_SKY_RES, VRT_DEVICE; VRT_PRESENT=1 copies every frame's 8-bit image to the host
+like the reference's window loop shows it (asynchronously, a frame behind: Renderer.present_async).
 """
 import os
 import sys
@@ -109,15 +110,22 @@ class Scene:
         aspect = SCREEN_RES[0] / SCREEN_RES[1]
         proj = cam_mod.perspective(r.fov[None], aspect, cam_mod.Z_NEAR, cam_mod.Z_FAR)
         view = cam_mod.look_at(self.camera.position, self.camera.look_at, UP_DIR)
+        present = bool(int(os.environ.get("VRT_PRESENT", 0)))
         t0 = time.time()
-        for _ in range(frames):
+        for k in range(frames):
             r.set_max_samples(999999999.0)
             r.set_render_scale(1.0)
             r.set_camera_is_moving(False)
             r.set_proj_mat(cam_mod.to_glm_memory(proj))
             r.set_view_mat(cam_mod.to_glm_memory(view))
             r.accumulate(samples_per_frame)
+            if present:   # scene.py:260 fetch_image() / canvas.set_image(): frame k - 1 is on the host while frame k renders
+                r.present_async(k)
+                if k:
+                    self.presented = r.present_wait(k - 1)
             r.copy_prev_matrices()
+        if present and frames:
+            self.presented = r.present_wait(frames - 1)
         r.session.sync()
         dt = time.time() - t0
         n = frames * samples_per_frame

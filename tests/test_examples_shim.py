@@ -1,7 +1,11 @@
 """The reference's example scripts run UNMODIFIED against this repo's `scene.py` + host-side `taichi`
 module.  On this CPU-only box the GPU renderer is replaced by a recorder that keeps
 the voxel grid the script authors, so what is tested is the Scene API surface and the DSL shim.  The scripts
-are read from /root/reference at test time (never copied); without the reference tree the tests skip."""
+are read from /root/reference at test time (never copied); without the reference tree the tests skip.
+Every run is also compared EXACTLY with tests/golden/examples.json (sha256 of the authored voxel arrays and every scene
+parameter, written by tests/golden/make_example_fixtures.py): a voxel that moves fails the hash, not just a range."""
+import hashlib
+import json
 import os
 import runpy
 import sys
@@ -39,6 +43,16 @@ class RecorderRenderer(VoxelStore):
     def prepare_data(self): self.calls.append("prepare_data")
 
 
+FIXTURE = json.load(open(os.path.join(ROOT, "tests", "golden", "examples.json")))
+
+
+def check_fixture(name, r):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_example_fixtures import describe
+    got, want = describe(r), FIXTURE[name]
+    assert got == want, {k: (got[k], want[k]) for k in want if got.get(k) != want[k]}
+
+
 def run_example(name, monkeypatch, tmp_path):
     import scene
     RecorderRenderer.instances.clear()
@@ -50,7 +64,16 @@ def run_example(name, monkeypatch, tmp_path):
     taichi.seed(0)
     runpy.run_path(os.path.join(REF, name), run_name="__main__")
     assert len(RecorderRenderer.instances) == 1
+    check_fixture(name, RecorderRenderer.instances[0])
     return RecorderRenderer.instances[0]
+
+
+def test_example6_grid_fixture_is_the_scripts_grid(monkeypatch, tmp_path):
+    """tests/golden/example6_grid.npz (what the GPU box renders in place of the script, tests/test_gpu_parity.py) holds exactly
+    the arrays example6.py authors."""
+    r = run_example("example6.py", monkeypatch, tmp_path)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "example6_grid.npz"))
+    assert np.array_equal(g["voxel_material"], r.voxel_material) and np.array_equal(g["voxel_color"], r.voxel_color)
 
 
 def test_example1(monkeypatch, tmp_path):

@@ -15,8 +15,8 @@ REL_L2_TOL = 1e-4  # the tolerance north_star states for the HDR buffer
 
 @pytest.fixture(autouse=True, params=["pool", "fused"])
 def render_schedule(request, monkeypatch):
-    """Every test runs under both schedules of the render stage (vrt_pool.h / vrt_path.h); contexts that cannot
-    use the pooled kernel (ReSTIR) run the fused one either way."""
+    """Every test runs under both schedules of the render stage (vrt_pool.h / vrt_path.h), ReSTIR contexts included
+    (k_render_pool_restir / k_render<restir>); frames beyond the pooled kernel's packing limits run the fused one either way."""
     monkeypatch.setenv("VRT_RENDER", request.param)
     return request.param
 
@@ -280,6 +280,40 @@ def test_restir_with_sky_matches_oracle(W, H):
     a, b = g.fetch_hdr(), o.fetch_hdr()
     assert rel_l2(a, b) <= REL_L2_TOL
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_example6_authored_grid_matches_oracle():
+    """The grid the reference's example6.py authors (tests/golden/example6_grid.npz: the arrays the script writes through this
+    repo's Scene API and DSL shim, tests/golden/make_example_fixtures.py; tests/test_examples_shim.py checks on the build host that
+    the file IS the script's grid), with the scene parameters the script sets (tests/golden/examples.json), rendered at 320x180
+    with physical sky + clouds and ReSTIR -- BASELINE config 3's scene, where bench.py uses the restatement scenes.scene_s6 --
+    against the oracle.  The sky tables at test size (R = 64: the oracle needs seconds per column at 3840)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    grid = np.load(os.path.join(root, "tests", "golden", "example6_grid.npz"))
+    ex = json.load(open(os.path.join(root, "tests", "golden", "examples.json")))["example6.py"]
+    assert int((grid["voxel_material"] != 0).sum()) == ex["solid"]
+    cloud = np.load(os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "data", "cloud_texture.npy"))
+    params = dict(floor_height=ex["floor_height"], floor_color=ex["floor_color"], floor_material=ex["floor_material"],
+                  background_color=ex["background_color"], light_direction=ex["light"]["direction"], light_cone=ex["light"]["cone"],
+                  light_color=ex["light"]["color"], use_physical_sky=ex["use_physical_sky"], use_clouds=ex["use_clouds"])
+    W, H, R = 320, 180, 64
+    cfg = host.make_config(W, H, voxel_edges=ex["voxel_edges"], exposure=ex["exposure"], max_depth=8, seed=6, sky_res=R, use_restir=True)
+    g, o = gpu_session(cfg), orc.Oracle(cfg, threads=16)
+    for s in (g, o):
+        orc.setup(s, grid["voxel_material"], grid["voxel_color"], params, cloud=cloud)
+        for _ in range(2):
+            s.sky_accumulate_clouds(2)
+        for sl in range(4):
+            s.sky_compute_slice(sl, 4)
+        s.accumulate(2)
+    a, b = g.fetch_hdr(), o.fetch_hdr()
+    assert np.isfinite(b).all() and b.mean() > 0.01
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a != b).sum()} of {a.size} values differ"
+    for which in (_abi.BUF_GBUF_DEPTH, _abi.BUF_GBUF_NORMAL, _abi.BUF_GBUF_MAT):
+        assert np.array_equal(g.fetch_buffer(which).view(np.uint8), o.fetch_buffer(which).view(np.uint8)), which
+    g.close(); o.close()
 
 
 def test_scene_api_end_to_end(tmp_path, monkeypatch):

@@ -229,7 +229,8 @@ def test_frames_presented_asynchronously():
     a, b = _session(cfg, mat, rgb, params), _session(cfg, mat, rgb, params)
     ldr = [a.host_alloc((H, W, 4)) for _ in range(2)]
     hdr = [a.host_alloc((H, W, 3)) for _ in range(2)]
-    shown = []
+    ldr8 = a.host_alloc((H, W, 4), np.uint8)
+    shown, shown8 = [], []
     for k in range(7):
         a.accumulate(4)
         a.fetch_ldr_async(ldr[k % 2], slot=k % 2)
@@ -239,11 +240,14 @@ def test_frames_presented_asynchronously():
             shown.append((ldr[(k - 1) % 2].copy(), hdr[(k - 1) % 2].copy()))
     a.fetch_wait(6 % 2); a.fetch_wait(2 + 6 % 2)
     shown.append((ldr[0].copy(), hdr[0].copy()))
+    a.fetch_ldr8_async(ldr8, slot=0)      # the 8-bit image of the last frame: what scene.save_image makes of the f32 one
+    a.fetch_wait(0)
     for k in range(7):
         b.accumulate(4)
         want_l, want_h = b.fetch_ldr(), b.fetch_hdr()
         assert np.array_equal(shown[k][0].view(np.uint32), want_l.view(np.uint32)), k
         assert np.array_equal(shown[k][1].view(np.uint32), want_h.view(np.uint32)), k
+    assert np.array_equal(ldr8, (np.clip(want_l, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8))
     a.close(); b.close()
 
 

@@ -6,7 +6,8 @@ CASE=${1:-config2}; TAG=${2:-pmc}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-# counters are per kernel: isolated launches (the library also turns overlapped launches off under --pmc, where they hang)
+# counters are per kernel: isolated launches, so that a launch's counters are its own (the default schedule also completes under
+# --pmc since round 2: the library leaves the dispatch gate out where its self-test finds queue operations serialised)
 export VRT_OVERLAP=0
 run() { name=$1; shift; timeout -k 10 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python $ROOT/tools/bench_scenes.py $CASE > $OUT/$name.log 2>&1; }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU

@@ -81,6 +81,7 @@ def declare(lib, prefix):
     sig("fetch_ldr", C.c_int, P, P)
     sig("fetch_hdr_async", C.c_int, P, P, C.c_int)
     sig("fetch_ldr_async", C.c_int, P, P, C.c_int)
+    sig("fetch_ldr8_async", C.c_int, P, P, C.c_int)
     sig("fetch_wait", C.c_int, P, C.c_int)
     sig("host_alloc", C.c_int, P, C.c_uint64, C.POINTER(C.c_void_p))
     sig("host_free", C.c_int, P, P)

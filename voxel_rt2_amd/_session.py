@@ -157,6 +157,10 @@ class NativeSession:
         assert out.dtype == np.float32 and out.shape == (self.H, self.W, 4) and out.flags.c_contiguous
         self._call("fetch_ldr_async", out.ctypes.data_as(C.c_void_p), int(slot))
 
+    def fetch_ldr8_async(self, out, slot=0):
+        assert out.dtype == np.uint8 and out.shape == (self.H, self.W, 4) and out.flags.c_contiguous
+        self._call("fetch_ldr8_async", out.ctypes.data_as(C.c_void_p), int(slot))
+
     def fetch_wait(self, slot=0):
         self._call("fetch_wait", int(slot))
 

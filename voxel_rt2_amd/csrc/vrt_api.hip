@@ -84,6 +84,7 @@ struct vrt_ctx {
     float *d_gb_refl = nullptr, *d_gb_refl_f = nullptr;
     f4 *d_hist_d[2] = {nullptr, nullptr}, *d_hist_s[2] = {nullptr, nullptr};
     f4* d_ldr = nullptr;
+    uint32_t* d_ldr8 = nullptr;   // rgba8 image of vrt_fetch_ldr8_async (allocated on first use)
     ReservoirRec* d_res[2] = {nullptr, nullptr};
     ReservoirRec* d_res_planes = nullptr;   // input reservoirs: VRT_MAX_FUSED planes, d_res[0] is the last of them
     GrisGeo* d_gris_geo = nullptr;   // per-pixel records of k_gris's prepare pass (vrt_restir.h)
@@ -420,7 +421,7 @@ void vrt_destroy(vrt_ctx* c) {
                     c->d_sky_trans, c->d_cloud_ambient, c->d_trans_lut, c->d_cloud_tex, c->d_cbuf[0], c->d_cbuf[1], c->d_spec_planes, c->d_color_d2,
                     c->d_color_s2, c->d_gb_pos, c->d_gb_normal[0], c->d_gb_normal[1], c->d_gb_depth[0], c->d_gb_depth[1],
                     c->d_gb_mat, c->d_refl_planes, c->d_gb_refl_f, c->d_hist_d[0], c->d_hist_d[1], c->d_hist_s[0], c->d_hist_s[1],
-                    c->d_ldr, c->d_res[1], c->d_res_planes, c->d_multi_d, c->d_pool_scratch, c->d_gris_geo, c->d_gris_src, c->d_mats_x};
+                    c->d_ldr, c->d_ldr8, c->d_res[1], c->d_res_planes, c->d_multi_d, c->d_pool_scratch, c->d_gris_geo, c->d_gris_src, c->d_mats_x};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (c->stream && c->owns_stream) hipStreamDestroy(c->stream);
@@ -585,7 +586,7 @@ static int record(vrt_ctx* c, int kind, hipEvent_t* a, hipEvent_t* b) {
 }
 
 // Second copies, streams and events for overlapped launches; false (and never tried again) if they cannot be had.
-static bool ensure_overlap(vrt_ctx* c) {
+static bool ensure_overlap(vrt_ctx* c, int g) {   // g: samples of the launch that sets the pipeline up (the caller's habit: 1 or VRT_MAX_FUSED)
     if (c->overlap_ready) return true;
     if (c->overlap_failed) return false;
     const size_t n = c->npix;
@@ -599,7 +600,7 @@ static bool ensure_overlap(vrt_ctx* c) {
     // VRT_DEEP_ITEMS: largest launch (pixels x fused samples) that gets the deep pipeline; VRT_STREAMS / VRT_GRID_DIV override.
     size_t deep_items = (size_t)12 << 20;
     if (const char* e = getenv("VRT_DEEP_ITEMS")) deep_items = (size_t)atoll(e);
-    const size_t items = (size_t)c->cfg.width * (size_t)(c->own1 - c->own0) * VRT_MAX_FUSED;
+    const size_t items = (size_t)c->cfg.width * (size_t)(c->own1 - c->own0) * (size_t)g;
     const bool deep = items <= deep_items;
     // Deeper still for the smallest frames -- one rank's rows of an 8-GPU split of 1080p are 1 M items a launch: eight launches
     // of a quarter of the slots each (profiles/r02_pipeline_depth.txt: +7.5 % on those rows, +1 % on half a frame, nothing on a
@@ -755,7 +756,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         if ((g > 1 || want_overlap) && !c->d_multi_d) {
             if (dalloc(&c->d_multi_d, c->npix * VRT_MAX_FUSED) != hipSuccess) { (void)hipGetLastError(); c->d_multi_d = nullptr; g = 1; want_overlap = false; }  // no memory: one launch per sample
         }
-        const bool overlapped = want_overlap && ensure_overlap(c);
+        const bool overlapped = want_overlap && ensure_overlap(c, g);
         const bool planes = g > 1 || overlapped;   // the launch writes colour planes of its own, not the HDR buffer
         const int set = overlapped ? (int)(c->pipe_seq % (unsigned)(c->n_streams + 1)) : 0;
         const int lane_of = (int)(c->pipe_seq % (unsigned)c->n_streams);  // which render stream (and pool scratch): consecutive launches take turns
@@ -996,18 +997,24 @@ static int ensure_fetch_stream(vrt_ctx* c) {
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fetch_src, hipEventDisableTiming));
     return VRT_OK;
 }
-static int fetch_async(vrt_ctx* c, void* out, int slot, bool ldr) {
+static int fetch_async(vrt_ctx* c, void* out, int slot, int what /* 0 HDR, 1 LDR f32 x 4, 2 LDR 8 bit x 4 */) {
+    const bool ldr = what != 0;
     if (!c || !out || slot < 0 || slot >= VRT_FETCH_SLOTS) return fail(VRT_E_INVALID, "bad argument (slot must be 0..3)");
     if (ldr && !c->have_cam) return fail(VRT_E_STATE, "vrt_set_camera has not been called");
     HIP_TRY(hipSetDevice(c->device));
+    if (what == 2 && !c->d_ldr8 && dalloc(&c->d_ldr8, c->npix) != hipSuccess) { c->d_ldr8 = nullptr; return fail(VRT_E_DEVICE, "no memory for the 8-bit image"); }
     if (ensure_fetch_stream(c) != VRT_OK) return VRT_E_DEVICE;
     const size_t W = c->cfg.width, rows = (size_t)(c->own1 - c->own0), off = (size_t)(c->own0 - c->buf0) * W;
     const int b = c->cidx;
     HIP_TRY(hipEventRecord(c->ev_fetch_src, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->fetch_stream, c->ev_fetch_src, 0));
-    if (ldr) {
-        HIP_TRY(launch_tonemap(c->fetch_stream, make_frame_params(c), c->d_cbuf[b], c->d_ldr, c->own0, c->own1));
+    if (what == 2) {
+        HIP_TRY(launch_tonemap8(c->fetch_stream, make_frame_params(c), c->d_cbuf[b], c->d_ldr8, c->own0, c->own1));
         HIP_TRY(hipEventRecord(c->ev_cbuf_read[b], c->fetch_stream));   // the HDR buffer is free again once the tonemap has read it
+        HIP_TRY(hipMemcpyAsync((char*)out + (size_t)c->own0 * W * 4, (const char*)c->d_ldr8 + off * 4, rows * W * 4, hipMemcpyDeviceToHost, c->fetch_stream));
+    } else if (ldr) {
+        HIP_TRY(launch_tonemap(c->fetch_stream, make_frame_params(c), c->d_cbuf[b], c->d_ldr, c->own0, c->own1));
+        HIP_TRY(hipEventRecord(c->ev_cbuf_read[b], c->fetch_stream));
         HIP_TRY(hipMemcpyAsync((char*)out + (size_t)c->own0 * W * sizeof(f4), (const char*)c->d_ldr + off * sizeof(f4), rows * W * sizeof(f4), hipMemcpyDeviceToHost, c->fetch_stream));
     } else {
         HIP_TRY(hipMemcpyAsync((char*)out + (size_t)c->own0 * W * sizeof(f3), (const char*)c->d_cbuf[b] + off * sizeof(f3), rows * W * sizeof(f3), hipMemcpyDeviceToHost, c->fetch_stream));
@@ -1018,8 +1025,9 @@ static int fetch_async(vrt_ctx* c, void* out, int slot, bool ldr) {
     c->fetch_valid[slot] = true;
     return VRT_OK;
 }
-int vrt_fetch_hdr_async(vrt_ctx* c, float* out, int slot) { return fetch_async(c, out, slot, false); }
-int vrt_fetch_ldr_async(vrt_ctx* c, float* out, int slot) { return fetch_async(c, out, slot, true); }
+int vrt_fetch_hdr_async(vrt_ctx* c, float* out, int slot) { return fetch_async(c, out, slot, 0); }
+int vrt_fetch_ldr_async(vrt_ctx* c, float* out, int slot) { return fetch_async(c, out, slot, 1); }
+int vrt_fetch_ldr8_async(vrt_ctx* c, uint8_t* out, int slot) { return fetch_async(c, out, slot, 2); }
 int vrt_fetch_wait(vrt_ctx* c, int slot) {
     if (!c || slot < 0 || slot >= VRT_FETCH_SLOTS) return fail(VRT_E_INVALID, "bad argument (slot must be 0..3)");
     if (!c->fetch_valid[slot]) return VRT_OK;

@@ -54,6 +54,7 @@ hipError_t launch_mat_derived(hipStream_t st, const float* mats, float* mats_x /
 hipError_t launch_gris(hipStream_t st, int grid_res, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1);
 hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1, int n_samples);
 hipError_t launch_tonemap(hipStream_t st, const FrameParams& fp, const f3* hdr, f4* ldr, int r0, int r1);
+hipError_t launch_tonemap8(hipStream_t st, const FrameParams& fp, const f3* hdr, uint32_t* ldr8 /* rgba, 8 bits each */, int r0, int r1);
 hipError_t launch_diag_read(hipStream_t st, unsigned long long* out, int reset);  // -DVRT_DIAG_REGIONS builds only
 hipError_t launch_detmath_probe(hipStream_t st, int op, int n, const float* a, const float* b, float* out);
 

@@ -691,6 +691,16 @@ __global__ __launch_bounds__(256) void k_tonemap(FrameParams fp, const f3* hdr, 
     const int v = r0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (u < fp.W && v < r1) ldr[(v - fp.row0) * fp.W + u] = tonemap_pixel(fp, hdr, u, v);
 }
+// the same image as 8-bit rgba for a display or a PNG: u8(clamp(c, 0, 1) * 255 + 0.5), the conversion scene.py's image writer does
+__global__ __launch_bounds__(256) void k_tonemap8(FrameParams fp, const f3* hdr, uint32_t* ldr8, int r0, int r1) {
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int v = r0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u < fp.W && v < r1) {
+        const f4 c = tonemap_pixel(fp, hdr, u, v);
+        ldr8[(v - fp.row0) * fp.W + u] = dm_f2u32(dm_saturate(c.x) * 255.0f + 0.5f) | (dm_f2u32(dm_saturate(c.y) * 255.0f + 0.5f) << 8) |
+                                         (dm_f2u32(dm_saturate(c.z) * 255.0f + 0.5f) << 16) | (dm_f2u32(dm_saturate(c.w) * 255.0f + 0.5f) << 24);
+    }
+}
 #if defined(VRT_DIAG_REGIONS)
 __global__ void k_diag_read(unsigned long long* out, int reset) {
     int i = threadIdx.x;
@@ -847,6 +857,12 @@ hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const Temporal
 hipError_t launch_tonemap(hipStream_t st, const FrameParams& fp, const f3* hdr, f4* ldr, int r0, int r1) {
     dim3 g((fp.W + 63) / 64, (r1 - r0 + 3) / 4), b(256);
     hipLaunchKernelGGL(k_tonemap, g, b, 0, st, fp, hdr, ldr, r0, r1);
+    VRT_LAUNCH_CHECK();
+    return hipSuccess;
+}
+hipError_t launch_tonemap8(hipStream_t st, const FrameParams& fp, const f3* hdr, uint32_t* ldr8, int r0, int r1) {
+    dim3 g((fp.W + 63) / 64, (r1 - r0 + 3) / 4), b(256);
+    hipLaunchKernelGGL(k_tonemap8, g, b, 0, st, fp, hdr, ldr8, r0, r1);
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }

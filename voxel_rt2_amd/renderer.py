@@ -231,6 +231,20 @@ class Renderer(VoxelStore):
     def fetch_hdr(self):
         return self._s.fetch_hdr()
 
+    # The reference shows every frame (scene.py:255-262: accumulate, fetch_image, canvas.set_image).  A blocking fetch_image
+    # waits for every launch queued so far; these two queue the tonemap and the copy of an 8-bit image behind the frame and
+    # return, so the caller can queue the next frame and pick the image up a frame later (two slots alternate).
+    def present_async(self, slot=0):
+        self._push()
+        if not hasattr(self, "_present"):
+            self._present = [self._s.host_alloc((self.image_res[1], self.image_res[0], 4), np.uint8) for _ in range(2)]
+        self._s.fetch_ldr8_async(self._present[slot & 1], slot & 1)
+
+    def present_wait(self, slot=0):
+        """rgba8 [H, W, 4] (row 0 = bottom) of the frame present_async(slot) was called on."""
+        self._s.fetch_wait(slot & 1)
+        return self._present[slot & 1]
+
     def stats(self):
         return self._s.stats()
 
