@@ -615,11 +615,14 @@ __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attr
 #ifndef VRT_GRIS_MIN_WAVES
 #define VRT_GRIS_MIN_WAVES 2   // whole pass: 256 registers, no spills; one wave per SIMD left the VALU idle a third of the time (6.6 vs 10.2 ms)
 #endif
+#ifndef VRT_GRIS_MIN_WAVES_A
+#define VRT_GRIS_MIN_WAVES_A 3 // first half: 168 registers, no spills
+#endif
 #ifndef VRT_GRIS_MIN_WAVES_B
 #define VRT_GRIS_MIN_WAVES_B 3 // second half: 168 registers hold it once the output reservoir carries the chosen TAP instead of its sample
 #endif
 template <int G, bool INSTR, int PHASE = 0>
-__global__ __launch_bounds__(256, (PHASE == 1 ? 3 : PHASE == 2 ? VRT_GRIS_MIN_WAVES_B : VRT_GRIS_MIN_WAVES)) void k_gris(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r_first, int r1, int tiles_x, int band_w) {
+__global__ __launch_bounds__(256, (PHASE == 1 ? VRT_GRIS_MIN_WAVES_A : PHASE == 2 ? VRT_GRIS_MIN_WAVES_B : VRT_GRIS_MIN_WAVES)) void k_gris(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r_first, int r1, int tiles_x, int band_w) {
     constexpr int N1 = GridDim<G>::n1 * GridDim<G>::n1 * GridDim<G>::n1, N2 = GridDim<G>::n2 * GridDim<G>::n2 * GridDim<G>::n2;
     __shared__ unsigned long long s_l1[N1];
     __shared__ unsigned long long s_l2[N2];
