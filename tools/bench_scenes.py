@@ -30,6 +30,12 @@ CASES = [
     # one rank's share of an 8- and a 2-GPU run of config 2 (rows through the middle of the picture)
     dict(name="shard_1of8_config2", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=20, rows=(472, 607)),
     dict(name="shard_1of2_config2", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=20, rows=(0, 540)),
+    dict(name="shard_1of4_config2", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=20, rows=(405, 675)),
+    # one rank's share of config 4 / config 5 on 2, 4 and 8 GPUs (the dense fill costs the same everywhere)
+    dict(name="shard_1of2_config4", scene="dense", W=3840, H=2160, depth=8, spp=4, steps=6, rows=(0, 1080)),
+    dict(name="shard_1of4_config4", scene="dense", W=3840, H=2160, depth=8, spp=4, steps=8, rows=(540, 1080)),
+    dict(name="shard_1of8_config4", scene="dense", W=3840, H=2160, depth=8, spp=4, steps=12, rows=(1080, 1350)),
+    dict(name="shard_1of8_config5", scene="dense256", W=3840, H=2160, depth=8, spp=4, steps=12, rows=(1080, 1350), grid=256),
     # the reference's own loop shape: one sample per call, a new jitter and vrt_end_frame every frame (scene.py:177, 233-262)
     dict(name="scene_api_default_1080p", scene="s1", W=1920, H=1080, depth=8, spp=1, steps=120, per_frame_camera=True),
 ]
@@ -39,7 +45,7 @@ def run(case):
     if os.environ.get("VRT_BENCH_STEPS"):   # longer runs: a deep launch pipeline takes a few steps to fill and to drain
         case = dict(case, steps=int(os.environ["VRT_BENCH_STEPS"]))
     lib = _lib.load()
-    mat, rgb, params = scenes.SCENES[case["scene"]](12345 if case["scene"] == "dense" else 0)
+    mat, rgb, params = scenes.SCENES[case["scene"]](12345 if case["scene"].startswith("dense") else 0)
     sky_res = case.get("sky_res", 0)
     if not sky_res:
         params = dict(params, use_physical_sky=0, use_clouds=0)
