@@ -83,8 +83,10 @@ def run(case):
     # collecting frame k - 1 while frame k renders -- the reference's accumulate / fetch_image loop (scene.py:255-262)
     fetch_each = os.environ.get("VRT_BENCH_FETCH_EACH", "")
     sync_each = bool(os.environ.get("VRT_BENCH_SYNC_EACH"))   # a caller that looks at every frame: no two launches in flight
-    # "async8": the same with the 8-bit image (vrt_fetch_ldr8_async), a quarter of the bytes
-    pinned = ([s.host_alloc((case["H"], case["W"], 4), np.uint8 if fetch_each == "async8" else np.float32) for _ in range(2)]
+    # "async8": the same with the 8-bit image (vrt_fetch_ldr8_async), a quarter of the bytes.  VRT_BENCH_FETCH_LAG (default 1):
+    # how many frames behind the caller collects (2: frame k - 2 while frames k - 1 and k render)
+    lag = int(os.environ.get("VRT_BENCH_FETCH_LAG", 1))
+    pinned = ([s.host_alloc((case["H"], case["W"], 4), np.uint8 if fetch_each == "async8" else np.float32) for _ in range(lag + 1)]
               if fetch_each in ("async", "async8") else None)
     cams = [host.default_camera(case["W"], case["H"], jitter_index=k + 1) for k in range(16)] if case.get("per_frame_camera") else None
     for k in range(case["steps"]):
@@ -96,13 +98,14 @@ def run(case):
         if sync_each:
             s.sync()
         if pinned:
-            (s.fetch_ldr8_async if fetch_each == "async8" else s.fetch_ldr_async)(pinned[k % 2], slot=k % 2)
-            if k:
-                s.fetch_wait((k - 1) % 2)
+            (s.fetch_ldr8_async if fetch_each == "async8" else s.fetch_ldr_async)(pinned[k % (lag + 1)], slot=k % (lag + 1))
+            if k >= lag:
+                s.fetch_wait((k - lag) % (lag + 1))
         elif fetch_each:
             s.fetch_hdr()
     if pinned:
-        s.fetch_wait((case["steps"] - 1) % 2)
+        for k in range(max(case["steps"] - lag, 0), case["steps"]):
+            s.fetch_wait(k % (lag + 1))
     s.sync()
     dt = time.perf_counter() - t0
     st = s.stats()

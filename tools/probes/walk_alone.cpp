@@ -5,8 +5,9 @@
 // passes run at 28-42 of 64 lanes because a wave only has the rays of its own 128-slot pool.  The round-2 review asked what a
 // separate persistent WALK kernel (about 100 registers, four waves per SIMD, rays exchanged through rings in L2) would gain.
 // This probe measures the UPPER BOUND of that design without building the rings: prepared walks (RayWalk records, 64 bytes) of
-// real ray populations lie in a global array, every wave owns a contiguous stretch of it and refills idle lanes in the loop
-// exactly as the WALK stage does (so the loop runs full until the stretch is used up), results go back as 16-byte records.
+// real ray populations lie in a global array, ONE resident grid of 1..8 waves per SIMD walks them, every wave owning a
+// contiguous stretch (hundreds of rays) and refilling idle lanes in the loop exactly as the WALK stage does (so the loop runs
+// full until the stretch is used up); results go back as 16-byte records.
 // No SHADE beside it, no LDS pools, no ring synchronisation: what it reaches is what the split could reach at best for the
 // WALK share of a launch.  Ray populations: camera rays of the bench camera, and the first and second bounce rays from their
 // hit points (cosine-distributed about the face normal) -- on the sparse S1-style scene and on the dense random fill.
@@ -180,13 +181,16 @@ __global__ void k_bounce(const WalkRec* prev, const WalkOut* res, WalkRec* recs,
     recs[i] = r;
 }
 
-template <int MINW>
-static int run(const char* label, Tables tb, const WalkRec* recs, WalkOut* out, int n, unsigned long long* d_cnt, int n_cu, int per_wave) {
+// One resident grid: n_cu x `occ` workgroups of four waves = `occ` waves per SIMD, every wave a stretch of n / waves rays (the
+// kernel needs 55 registers, so up to eight waves per SIMD fit: occupancy is set by the grid, not by the register budget).
+static int run(const char* label, Tables tb, const WalkRec* recs, WalkOut* out, int n, unsigned long long* d_cnt, int n_cu, int occ) {
+    constexpr int MINW = 2;
     int per_cu = 0;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_walk<MINW>, 256, 0));
     hipFuncAttributes fa;
     CK(hipFuncGetAttributes(&fa, (const void*)k_walk<MINW>));
-    const int waves = (n + per_wave - 1) / per_wave, blocks = (waves + 3) / 4;
+    if (occ > per_cu) occ = per_cu;
+    const int blocks = n_cu * occ, waves = blocks * 4, per_wave = (n + waves - 1) / waves;
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     float best = 1e30f;
@@ -202,10 +206,9 @@ static int run(const char* label, Tables tb, const WalkRec* recs, WalkOut* out, 
         if (ms < best) best = ms;
         CK(hipMemcpy(cnt, d_cnt, 16, hipMemcpyDeviceToHost));
     }
-    printf("  %-8s %d waves/SIMD asked (%3d VGPR, %d workgroups per CU = %d waves/SIMD resident), %5d rays per wave: %7.3f ms  %6.1f G lane-steps/s  "
-           "%5.1f of 64 lanes per trip  %5.2f steps per ray\n", label, MINW, fa.numRegs, per_cu, per_cu, per_wave, best, (double)cnt[0] / best * 1e-6,
+    printf("  %-8s %d waves/SIMD (%3d VGPR), %5d rays per wave: %7.3f ms  %6.1f G lane-steps/s  %5.2f G wave-trips/s  %5.1f of 64 lanes per trip  "
+           "%5.2f steps per ray\n", label, occ, fa.numRegs, per_wave, best, (double)cnt[0] / best * 1e-6, (double)cnt[1] / best * 1e-6,
            (double)cnt[0] / (double)cnt[1], (double)cnt[0] / n);
-    (void)n_cu;
     return 0;
 }
 
@@ -251,11 +254,8 @@ int main(int argc, char** argv) {
         if (k > 0) hipLaunchKernelGGL(k_bounce, dim3((n + 255) / 256), dim3(256), 0, 0, recs[k - 1], outs[k - 1], recs[k], n, 1234u * (uint32_t)k);
         CK(hipDeviceSynchronize());
         printf("%s rays:\n", names[k]);
-        for (int per_wave : {128, 1024}) {   // a pool's worth of rays per wave, and a long stretch (the loop's tail amortised)
-            if (run<2>(names[k], tb, recs[k], outs[k], n, d_cnt, prop.multiProcessorCount, per_wave)) return 1;
-            if (run<3>(names[k], tb, recs[k], outs[k], n, d_cnt, prop.multiProcessorCount, per_wave)) return 1;
-            if (run<4>(names[k], tb, recs[k], outs[k], n, d_cnt, prop.multiProcessorCount, per_wave)) return 1;
-        }
+        for (int occ : {1, 2, 3, 4, 6, 8})
+            if (run(names[k], tb, recs[k], outs[k], n, d_cnt, prop.multiProcessorCount, occ)) return 1;
     }
     return 0;
 }

@@ -763,9 +763,18 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         hipStream_t rs = overlapped ? c->rstream[lane_of] : c->stream;
         // A launch of half the slots only pays with other launches beside it: one that finds the pipeline empty (the caller
         // fetches every frame, or this is the first of a run) takes every slot like a launch that is not overlapped.
+        // The same holds for a pipeline that is nearly empty -- a caller that presents every frame and waits for frame k - 1
+        // before it queues frame k + 1 keeps one or two launches in flight, which as half-size launches leave half the chip idle:
+        // fewer than two launches still running means every slot.
         bool lone = !overlapped;
-        if (overlapped && c->grid_div > 1) lone = c->last_render_set < 0 || hipEventQuery(c->ev_r[c->last_render_set]) == hipSuccess;
-        (void)hipGetLastError();   // (hipErrorNotReady is the expected answer)
+        if (overlapped && c->grid_div > 1) {
+            int running = 0;
+            const unsigned n_sets = (unsigned)c->n_streams + 1u;
+            for (unsigned back = 1; back <= 3u && back <= c->pipe_seq && running < 2; back++)
+                if (hipEventQuery(c->ev_r[(c->pipe_seq - back) % n_sets]) == hipErrorNotReady) running++;
+            (void)hipGetLastError();   // (hipErrorNotReady is the expected answer)
+            lone = running < 2;
+        }
         if (overlapped) {
             if (c->main_dirty) {  // uploads / prepare / sky kernels queued on the main stream come first
                 HIP_TRY(hipEventRecord(c->ev_main, c->stream));
