@@ -770,10 +770,12 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         if (overlapped && c->grid_div > 1) {
             int running = 0;
             const unsigned n_sets = (unsigned)c->n_streams + 1u;
-            for (unsigned back = 1; back <= 3u && back <= c->pipe_seq && running < 2; back++)
+            for (unsigned back = 1; back <= 3u && back <= c->pipe_seq; back++)
                 if (hipEventQuery(c->ev_r[(c->pipe_seq - back) % n_sets]) == hipErrorNotReady) running++;
             (void)hipGetLastError();   // (hipErrorNotReady is the expected answer)
-            lone = running < 2;
+            int full_below = 2;   // VRT_FULL_BELOW=n: every slot while fewer than n launches are still running (A/B)
+            if (const char* e = getenv("VRT_FULL_BELOW")) { const int v = atoi(e); if (v >= 1 && v <= 3) full_below = v; }
+            lone = running < full_below;
         }
         if (overlapped) {
             if (c->main_dirty) {  // uploads / prepare / sky kernels queued on the main stream come first
