@@ -211,7 +211,9 @@ VRT_DEV bool cull_ray(const float* cull, f3 o, f3 d, float& t_exit) {
 }
 
 // raytracer.py:72-155 with ray_min_t = eps, ray_max_t = inf (the only call site, pathtracer.py:201-202).
-template <class PyrT>
+// FLAT: which descent (descend_flat / descend) -- by default what the pyramid type says suits its kernel; the shadow rays the
+// pooled kernel's SHADE stage walks inline run at ~15 of 64 lanes, where the branchy descent's early outs win (VRT_SHADOW_BRANCHY).
+template <class PyrT, bool FLAT = PyrT::flat_descend>
 VRT_DEV void raytrace(const PyrT& P, f3 o, f3 d, TraceOut& r, int& queries, const float* cull) {
     float hit_distance = DM_INF;
     int ix = -1, iy = -1, iz = -1;
@@ -262,7 +264,7 @@ VRT_DEV void raytrace(const PyrT& P, f3 o, f3 d, TraceOut& r, int& queries, cons
             bool solid;
             int nq;
             VRT_REGION(7);
-            if constexpr (PyrT::flat_descend) {  // the pyramid type says which descent suits its kernel (see descend_flat)
+            if constexpr (FLAT) {  // the pyramid type says which descent suits its kernel (see descend_flat)
                 CoarseWords c;
                 coarse_fetch(P, ix, iy, iz, c);
                 lod = descend_flat(P, c, ix, iy, iz, lod, solid, bc, nq);
@@ -465,7 +467,10 @@ VRT_DEV void next_hit(const FrameParams& fp, const SceneData& sc, const PyrT& P,
     const f3 eye = world_to_voxel<PyrT::G>(pos);
     TraceOut tr;
     int nq;
-    raytrace(P, eye, d, tr, nq, sc.cull);
+#ifndef VRT_SHADOW_BRANCHY
+#define VRT_SHADOW_BRANCHY 0
+#endif
+    raytrace<PyrT, PyrT::flat_descend && !(SHADOW && VRT_SHADOW_BRANCHY)>(P, eye, d, tr, nq, sc.cull);
     ts.rays += 1u; ts.iters += (unsigned)tr.iters; ts.queries += (unsigned)nq;
     VRT_REGION(SHADOW ? 3 : 9);  // ray set-up + result (one entry per ray)
     hit_voxel<SHADOW, PyrT::G>(fp, sc, eye, d, tr, h, ts);
