@@ -62,6 +62,7 @@ struct vrt_ctx {
     unsigned long long *d_l0 = nullptr, *d_l1 = nullptr, *d_l2 = nullptr, *d_l3 = nullptr, *d_l0c = nullptr;
     uint32_t* d_l0c_base = nullptr;  // [512] offsets + [1] count
     bool cull_active = false;        // the grown box leaves part of the grid out: there are rays to cull (read back by vrt_prepare)
+    bool dense_grid = false;         // half of the bricks or more are non-empty (read back by vrt_prepare)
     float* d_cull = nullptr;         // [8] grown bounding box of the solid voxels + flag, [8] the same with the flag off (cull_ray, vrt_trace.h)
     float* d_mats = nullptr;
     Counters* d_counters = nullptr;
@@ -502,6 +503,9 @@ int vrt_prepare(vrt_ctx* c) {
         HIP_TRY(hipMemcpyAsync(box, c->d_cull, sizeof(box), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));   // (source and destination are on this stack frame)
         c->cull_active = box[6] != 0.0f;
+        // at least half of the 4x4x4 bricks hold a voxel: a dense grid (shadow rays end after a step or two: launch_render_pool)
+        c->dense_grid = box[7] >= 0.5f;
+        if (const char* e = getenv("VRT_DENSE")) c->dense_grid = atoi(e) != 0;   // A/B
     }
     if (c->scene.use_physical_sky == 1) {
         SkyPrecompute sp = make_sky(c);
@@ -838,7 +842,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             prim = c->d_prim_cache[which];
         }
         const int blocks = lone ? c->render_blocks : (c->render_blocks / c->grid_div + 7) & ~7;  // whole rounds of the 8 XCDs
-        if (c->pooled) HIP_TRY(launch_render_pool(rs, c->cfg.grid_res, restir, instr, blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch[lane_of - 1] : c->d_pool_scratch, c->drain_signal, prim, culling(c)));
+        if (c->pooled) HIP_TRY(launch_render_pool(rs, c->cfg.grid_res, restir, instr, blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch[lane_of - 1] : c->d_pool_scratch, c->drain_signal, prim, culling(c), c->dense_grid));
         else HIP_TRY(launch_render(rs, c->cfg.grid_res, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g));
         c->drain_signalled = c->pooled && c->drain_signal != nullptr;
         c->prev_launch_full = blocks == c->render_blocks;

@@ -74,13 +74,17 @@ __global__ void k_build_coarse(const unsigned long long* __restrict__ fine, unsi
 // One block; an empty grid gives lo > hi.
 __global__ void k_cull_box(const unsigned long long* __restrict__ l0, int n0, float* __restrict__ out) {
     __shared__ int s_lo[3][256], s_hi[3][256];
+    __shared__ int s_cnt[256];
+    int cnt = 0;   // non-empty bricks
     int lo[3] = {1 << 20, 1 << 20, 1 << 20}, hi[3] = {-(1 << 20), -(1 << 20), -(1 << 20)};
     for (int b = threadIdx.x; b < n0 * n0 * n0; b += blockDim.x) {
         if (l0[b] == 0ULL) continue;
+        cnt++;
         const int c[3] = {b % n0, (b / n0) % n0, b / (n0 * n0)};
         for (int a = 0; a < 3; a++) { lo[a] = min(lo[a], c[a] * 4); hi[a] = max(hi[a], c[a] * 4 + 4); }
     }
     for (int a = 0; a < 3; a++) { s_lo[a][threadIdx.x] = lo[a]; s_hi[a][threadIdx.x] = hi[a]; }
+    s_cnt[threadIdx.x] = cnt;
     __syncthreads();
     if (threadIdx.x < 3) {
         int l = 1 << 20, h = -(1 << 20);
@@ -94,7 +98,9 @@ __global__ void k_cull_box(const unsigned long long* __restrict__ l0, int n0, fl
         bool some = false;
         for (int a = 0; a < 3; a++) some = some || out[a] > 0.0f || out[3 + a] < G;
         out[6] = some ? 1.0f : 0.0f;
-        out[7] = 0.0f;
+        int total = 0;
+        for (int i = 0; i < 256; i++) total += s_cnt[i];
+        out[7] = (float)total / (float)(n0 * n0 * n0);   // share of non-empty 4x4x4 bricks (read by the host: which SHADE variant; cull_ray does not look at it)
     }
 }
 
@@ -147,11 +153,12 @@ struct LdsPyramid {  // coarse levels in LDS, fine level through L2
 // hundred words, and the fine word is the load every other DDA step depends on (L2: ~700 cycles, LDS: ~130).
 // CULL: rays that cannot hit a voxel are not walked (cull_ray, vrt_trace.h).  A launch over a scene whose solids fill the grid
 // has nothing to cull and runs the instantiation without the test (its registers cost a dense 4K frame 2.5 %).
-template <int G_, bool CULL_>
+template <int G_, bool CULL_, bool SHBR_ = false>
 struct LdsPyramid2 {
     static constexpr int G = G_;
     static constexpr bool cull = CULL_;
     static constexpr bool flat_descend = true;   // the pooled kernel walks with nearly full waves
+    static constexpr bool shadow_branchy = SHBR_;   // ... except SHADE's inline shadow rays in a dense grid (raytrace, vrt_trace.h)
     const unsigned long long* l0;
     const ulonglong2* l12;
     const unsigned long long* l2;
@@ -175,11 +182,12 @@ struct LdsPyramid2 {
 // they miss LDS by a factor of 13) through L1 / L2 with the current brick's word cached in registers per ray.  A
 // workgroup is eight waves (one per CU: eight 13.5 KB path pools + 32.5 KB of pyramid + the material table = 148 KB of
 // the CU's 160 KB), so the level is staged once per CU.
-template <bool CULL_>
-struct LdsPyramid2<256, CULL_> {
+template <bool CULL_, bool SHBR_>
+struct LdsPyramid2<256, CULL_, SHBR_> {
     static constexpr int G = 256;
     static constexpr bool cull = CULL_;
     static constexpr bool flat_descend = true;
+    static constexpr bool shadow_branchy = SHBR_;
     const unsigned long long* l0;
     const unsigned long long* l1;   // LDS [4096]
     const unsigned long long* l2;   // LDS [64]
@@ -317,7 +325,7 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-template <int G, bool RESTIR, bool INSTR, bool BLACK_SUN, bool CULL>
+template <int G, bool RESTIR, bool INSTR, bool BLACK_SUN, bool CULL, bool SHBR = false>
 // 208 registers per wave (the attribute counts half of the unified file): two waves per SIMD then leave the 96 that
 // k_temporal runs in beside them (see there).  The allocator would take 238; the cap costs 28 bytes of scratch.
 // The ReSTIR instantiation (no overlapped launches, so nothing runs beside it) takes the two-wave maximum of 256.
@@ -337,7 +345,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
     __shared__ uint32_t s_pool[WAVES][PF_COUNT * VRT_POOL_SLOTS];
     __shared__ uint32_t s_state[WAVES][VRT_POOL_WORDS * 64];
     __shared__ uint32_t s_list[WAVES][VRT_POOL_SLOTS];
-    LdsPyramid2<G, CULL> P;
+    LdsPyramid2<G, CULL, SHBR> P;
     P.l0 = sc.pyr.l0; P.l2 = s_l2;
     if constexpr (BIG) {
         for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
@@ -602,6 +610,11 @@ template <int G, bool INSTR, bool BLACK_SUN, bool CULL>
 __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(VRT_POOL_HALF_VGPRS))) void k_render_pool(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
     render_pool_body<G, false, INSTR, BLACK_SUN, CULL>(fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, drain_value, prim_cache);
 }
+// a dense grid under an emitting sun: the shadow rays of SHADE with the branchy descent (shadow_branchy_of, vrt_trace.h)
+template <int G, bool INSTR, bool CULL>
+__global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(VRT_POOL_HALF_VGPRS))) void k_render_pool_dense(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
+    render_pool_body<G, false, INSTR, false, CULL, true>(fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, drain_value, prim_cache);
+}
 template <int G, bool INSTR, bool CULL>
 __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(128))) void k_render_pool_restir(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
     render_pool_body<G, true, INSTR, false, CULL>(fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, drain_value, prim_cache);
@@ -811,7 +824,7 @@ size_t pool_scratch_bytes(int grid_res, bool restir, int n_blocks) {
 }
 hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                               const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold,
-                              uint32_t* drain_signal, PrimaryRecord* prim_cache, bool cull) {
+                              uint32_t* drain_signal, PrimaryRecord* prim_cache, bool cull, bool dense) {
     unsigned* work_counter = work_counters + (launch_seq & 15u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     unsigned* next_counter = work_counters + ((launch_seq + 8u) & 15u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     dim3 g(n_blocks), b(64 * pool_waves_per_block(grid_res));
@@ -822,6 +835,8 @@ hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool in
     if (restir) {  // the reservoir needs the light sample whatever the sun's colour
         if (cull) VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_render_pool_restir<G, A, true>), VRT_POOL_ARGS)));
         else VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_render_pool_restir<G, A, false>), VRT_POOL_ARGS)));
+    } else if (dense && !black_sun) {   // (with a black sun SHADE walks next to no shadow rays)
+        VRT_BY_GRID(grid_res, VRT_BY_2(instr, cull, hipLaunchKernelGGL((k_render_pool_dense<G, A, B>), VRT_POOL_ARGS)));
     } else {
         if (cull) VRT_BY_GRID(grid_res, VRT_BY_2(instr, black_sun, hipLaunchKernelGGL((k_render_pool<G, A, B, true>), VRT_POOL_ARGS)));
         else VRT_BY_GRID(grid_res, VRT_BY_2(instr, black_sun, hipLaunchKernelGGL((k_render_pool<G, A, B, false>), VRT_POOL_ARGS)));

@@ -15,6 +15,7 @@
 #ifndef VRT_TRACE_H
 #define VRT_TRACE_H
 
+#include <type_traits>
 #include "vrt_types.h"
 
 namespace vrt {
@@ -211,8 +212,12 @@ VRT_DEV bool cull_ray(const float* cull, f3 o, f3 d, float& t_exit) {
 }
 
 // raytracer.py:72-155 with ray_min_t = eps, ray_max_t = inf (the only call site, pathtracer.py:201-202).
-// FLAT: which descent (descend_flat / descend) -- by default what the pyramid type says suits its kernel; the shadow rays the
-// pooled kernel's SHADE stage walks inline run at ~15 of 64 lanes, where the branchy descent's early outs win (VRT_SHADOW_BRANCHY).
+// FLAT: which descent (descend_flat / descend) -- by default what the pyramid type says suits its kernel.  A pyramid type may
+// also say `shadow_branchy`: the shadow rays the pooled kernel's SHADE stage walks inline run at ~15 of 64 lanes, where the
+// branchy descent's early outs win IN A DENSE GRID (a ray ends after 1.2 steps: dense 128^3 / 256^3 at 4K +3.8 %), while the
+// long shadow rays of a sparse scene lose (S6 -5.6 %): the launcher picks the instantiation by the share of non-empty bricks.
+template <class T, class = void> struct shadow_branchy_of { static constexpr bool value = false; };
+template <class T> struct shadow_branchy_of<T, std::void_t<decltype(T::shadow_branchy)>> { static constexpr bool value = T::shadow_branchy; };
 template <class PyrT, bool FLAT = PyrT::flat_descend>
 VRT_DEV void raytrace(const PyrT& P, f3 o, f3 d, TraceOut& r, int& queries, const float* cull) {
     float hit_distance = DM_INF;
@@ -467,10 +472,7 @@ VRT_DEV void next_hit(const FrameParams& fp, const SceneData& sc, const PyrT& P,
     const f3 eye = world_to_voxel<PyrT::G>(pos);
     TraceOut tr;
     int nq;
-#ifndef VRT_SHADOW_BRANCHY
-#define VRT_SHADOW_BRANCHY 0
-#endif
-    raytrace<PyrT, PyrT::flat_descend && !(SHADOW && VRT_SHADOW_BRANCHY)>(P, eye, d, tr, nq, sc.cull);
+    raytrace<PyrT, PyrT::flat_descend && !(SHADOW && shadow_branchy_of<PyrT>::value)>(P, eye, d, tr, nq, sc.cull);
     ts.rays += 1u; ts.iters += (unsigned)tr.iters; ts.queries += (unsigned)nq;
     VRT_REGION(SHADOW ? 3 : 9);  // ray set-up + result (one entry per ray)
     hit_voxel<SHADOW, PyrT::G>(fp, sc, eye, d, tr, h, ts);
