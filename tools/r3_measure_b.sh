@@ -1,22 +1,9 @@
-# round 3, the whole measurement pass on the build that ships, in one gpurun call:
-#   counters per config (tools/pmc.sh) -> profiles/traffic.json stamped with the build id (tools/make_traffic.py)
-#   kernel traces: the bench command (config 2) and one per secondary config (configs 3 / 4 / 5)
-#   scene table incl. the shards the scaling prediction uses, the present rates, then the judged line (bench.py)
-# Everything lands in gpurun_out/$TAG; copy what is to be judged into profiles/ on the build host.
-TAG=${1:-r3_final}; LABEL=${2:-$TAG}
+# round 3, the measurement pass, part B (after profiles/traffic.json of part A is in place): scene table incl. the shards the
+# scaling prediction uses, present rates, kernel traces of the bench command (config 2) and of configs 3 / 4 / 5, the default
+# schedule under --pmc, then the judged line (bench.py).  Everything lands in gpurun_out/$TAG.
+TAG=${1:-r3_final}
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-python -c "from voxel_rt2_amd import _lib; print(_lib.build_id())" > $O/build_id.txt 2>/dev/null
-ID=$(cat $O/build_id.txt); echo "build $ID"
-for c in config2_s1 config5_dense256 config4_dense config3_s6; do
-  bash tools/pmc.sh $c ${TAG}_pmc_$c > /dev/null 2>&1
-  python tools/pmc_summary.py $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$c > $O/pmc_$c.txt
-  echo "pmc $c: $(grep -c mean $O/pmc_$c.txt) rows"
-done
-python tools/make_traffic.py $ID "$LABEL" config2_s1_1080p=gpurun_out/${TAG}_pmc_config2_s1 config5_dense256_4k=gpurun_out/${TAG}_pmc_config5_dense256 \
-    config4_dense_4k=gpurun_out/${TAG}_pmc_config4_dense config3_s6_sky_clouds_restir_1080p=gpurun_out/${TAG}_pmc_config3_s6 > /dev/null || exit 1
-cp profiles/traffic.json $O/traffic.json
-rm -rf gpurun_out/${TAG}_pmc_*    # (raw counter csvs: tens of MB)
 python tools/bench_scenes.py > $O/scenes.jsonl 2> $O/scenes.err; echo "scenes: $(grep -c name $O/scenes.jsonl)"
 for mode in 1 async async8; do for lag in 1 2; do
   [ $mode == 1 ] && [ $lag == 2 ] && continue
