@@ -61,6 +61,8 @@ def main():
                                   ("k_render", "vrt::k_render<", 2), ("k_gris", "vrt::k_gris<", 1),
                                   ("k_gris_prepare", "vrt::k_gris_prepare", None), ("k_temporal", "vrt::k_temporal", None)):
             k, v = pick(m, prefix, ia)
+            if not v and short == "k_render_pool":   # the dense-grid variant of the same kernel (k_render_pool_dense<G, INSTR, CULL>)
+                k, v = pick(m, "vrt::k_render_pool_dense<", 1)
             if v and short == "k_gris":
                 # the spatial-reuse pass runs as two kernels (template argument 3 = 1, 2: vrt_restir.h): one entry, their counters summed
                 halves = [(kk, vv) for kk, vv in m.items() if kk.replace("void ", "").startswith(prefix)
