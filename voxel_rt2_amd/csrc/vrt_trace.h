@@ -352,9 +352,6 @@ VRT_DEV bool walk_prepare(f3 o, f3 d, RayWalk& w, const float* cull) {
 
 // One pass of the loop raytracer.py:103-147.  True = the walk is over (hit, miss or 512 steps).  `c` holds the
 // coarse words of the walk's current cell (coarse_fetch) on entry and of its next cell on return.
-#ifndef VRT_WALK_BRANCHY_DENSE
-#define VRT_WALK_BRANCHY_DENSE 0   // A/B: the WALK stage of the dense-grid variant with the branchy descent too
-#endif
 template <class PyrT>
 VRT_DEV bool walk_trip(const PyrT& P, RayWalk& w, BrickCache& bc, CoarseWords& c, int& nq) {
     nq = 0;
@@ -362,9 +359,8 @@ VRT_DEV bool walk_trip(const PyrT& P, RayWalk& w, BrickCache& bc, CoarseWords& c
     if (w.t > w.far) { w.t = DM_INF; return true; }
     bool solid;
     VRT_REGION(1);
-    constexpr bool branchy = VRT_WALK_BRANCHY_DENSE && shadow_branchy_of<PyrT>::value;
-    if constexpr (branchy) w.lod = descend(P, w.ix, w.iy, w.iz, w.lod, solid, bc, nq);
-    else w.lod = descend_flat(P, c, w.ix, w.iy, w.iz, w.lod, solid, bc, nq);
+    // (the branchy descent here too, in the dense-grid variant: -0.8 % / 0 on the dense 4K frames, profiles/README.md)
+    w.lod = descend_flat(P, c, w.ix, w.iy, w.iz, w.lod, solid, bc, nq);
     if (solid) return true;
     // The step of raytrace() with three of its values produced by cheaper, bit-identical means: 2^lod assembled from
     // its exponent, the cell base as float(ix with its low lod bits cleared) (= float(ix >> lod) * 2^lod: both exact),
@@ -387,7 +383,7 @@ VRT_DEV bool walk_trip(const PyrT& P, RayWalk& w, BrickCache& bc, CoarseWords& c
                t.z == min_t ? w.sd.z : dm_u2f(dm_f2u(w.sd.z) & 0x80000000u));
     const f3 nxt = cell_base + edge + w.hn;
     w.ix = (int)nxt.x; w.iy = (int)nxt.y; w.iz = (int)nxt.z;
-    if constexpr (!branchy) coarse_fetch(P, w.ix, w.iy, w.iz, c);
+    coarse_fetch(P, w.ix, w.iy, w.iz, c);
     w.lod = (lod + 1 > GridDim<PyrT::G>::max_lod) ? GridDim<PyrT::G>::max_lod : lod + 1;
     w.iters += 1;
     return false;
