@@ -47,8 +47,9 @@ DM_HD float dm_floor(float x) { return __builtin_floorf(x); }
  * WAVE-UNIFORM guard: if any lane of the wave holds an argument the wrapping would have acted on, the whole wave takes the
  * compiler's sequence (a scalar branch, never taken in practice) -- so the result is the correctly rounded one for EVERY
  * argument, by construction where the wrapping is the identity, by the compiler's code elsewhere.
- *   dm_sqrt: unwrapped for x = +-0, x >= 2^-96 (incl. +inf), x < 0 and NaN (all of which leave the unwrapped sequence as they
- *   leave the wrapped one); wrapped when 0 < x < 2^-96.
+ *   dm_sqrt: unwrapped for x = +-0, |x| >= 2^-96 (incl. +inf and the negative arguments, NaN either way) and NaN (all of which
+ *   leave the unwrapped sequence as they leave the wrapped one); wrapped when 0 < |x| < 2^-96 (the exhaustive test found the
+ *   negative denormals: v_sqrt_f32 returns -0 for them where the scaled sequence returns NaN).
  *   dm_rsqrt_sum (norm3: 1 / sqrt(x), two roundings as written): unwrapped for 2^-96 <= x < 2^126, then sqrt(x) lies in
  *   [2^-48, 2^63), where v_div_scale scales nothing and v_div_fixup passes the quotient through.
  * tests/test_gpu_parity.py::test_unwrapped_sqrt_and_reciprocal_over_all_floats compares both with the compiler's own
@@ -73,7 +74,7 @@ DM_HD float dm_rcp_unwrapped(float b) {
     return __builtin_fmaf(e2, y, q);
 }
 DM_HD float dm_sqrt(float x) {
-    const bool wrap = (__builtin_bit_cast(uint32_t, x) - 1u) < (0x0f800000u - 1u);   /* 0 < x < 2^-96 */
+    const bool wrap = __builtin_fabsf(x) < 0x1p-96f && x != 0.0f;   /* 0 < |x| < 2^-96 (a negative denormal: v_sqrt_f32 gives -0, the scaled sequence NaN) */
     if (__builtin_amdgcn_ballot_w64(wrap) != 0ULL) return __builtin_sqrtf(x);
     return dm_sqrt_unwrapped(x);
 }

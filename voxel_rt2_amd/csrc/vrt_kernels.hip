@@ -759,7 +759,7 @@ __global__ void k_detmath_probe(int op, int n, const float* a, const float* b, f
 
 // Every binary32 bit pattern through the unwrapped sqrt / reciprocal sequences of vrt_detmath.h and through the compiler's own:
 // out[k] = mismatches of check k, out[4 + k] = one mismatching pattern.  Checks: 0 dm_sqrt (guarded) against __builtin_sqrtf on
-// every pattern; 1 the unwrapped sqrt alone on its domain (everything but 0 < x < 2^-96); 2 dm_rsqrt_sum (guarded) against
+// every pattern; 1 the unwrapped sqrt alone on its domain (everything but 0 < |x| < 2^-96); 2 dm_rsqrt_sum (guarded) against
 // 1.0f / __builtin_sqrtf on every pattern; 3 the unwrapped reciprocal alone against 1.0f / b for 2^-96 <= |b| < 2^126.
 __global__ __launch_bounds__(256) void k_divsqrt_selftest(unsigned long long* out) {
     unsigned long long bad[4] = {0ULL, 0ULL, 0ULL, 0ULL};
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256) void k_divsqrt_selftest(unsigned long long* ou
 #if defined(DM_PLAIN_DIVSQRT) || !defined(__HIP_DEVICE_COMPILE__)   // (the host pass only parses this)
         got[1] = ref_s; in[1] = false; got[3] = ref_q; in[3] = false;
 #else
-        got[1] = dm_sqrt_unwrapped(x); in[1] = !((u - 1u) < (0x0f800000u - 1u));
+        got[1] = dm_sqrt_unwrapped(x); in[1] = !(dm_abs(x) < 0x1p-96f && x != 0.0f);
         got[3] = dm_rcp_unwrapped(x); in[3] = dm_abs(x) >= 0x1p-96f && dm_abs(x) < 0x1p126f;
 #endif
         const float want[4] = {ref_s, ref_s, ref_r, ref_q};
