@@ -203,10 +203,6 @@ const char* vrt_build_id(void);
  * op 0 sin 1 cos 2 exp 3 log 4 pow 5 acos 6 atan2 7 min 8 max 9 f16 round trip 10 a/b 11 sqrt
  * 12 a*b+a (uncontracted) 13 float->int. */
 int vrt_detmath_probe(int device, int op, int n, const float* a, const float* b, float* out);
-/* Numeric-contract test hook: every binary32 bit pattern through the device's square root and reciprocal-of-square-root as
- * vrt_detmath.h spells them (the compiler's correctly rounded sequences without their range scaling, behind a wave-uniform
- * guard) against the compiler's own; out[0..3] = mismatches of four checks (all must be 0), out[4..7] = a mismatching pattern. */
-int vrt_divsqrt_selftest(int device, uint64_t* out8);
 /* Diagnostic builds only (library compiled with -DVRT_DIAG_REGIONS, see tools/diag_regions.py): copy out the
  * 32 x {wave entries, active lanes} counters of the instrumented regions of the render kernel and optionally
  * zero them.  The shipped library returns VRT_E_STATE -- it carries no region counters. */

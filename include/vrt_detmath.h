@@ -38,55 +38,7 @@ DM_HD float dm_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 DM_HD float dm_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 DM_HD float dm_abs(float x) { return __builtin_fabsf(x); }
 DM_HD float dm_floor(float x) { return __builtin_floorf(x); }
-/* sqrt and 1 / sqrt-of-a-sum on the device: the compiler's correctly rounded sequences WITHOUT their range scaling.
- * hipcc expands a correctly rounded sqrt into 16 vector instructions -- v_sqrt_f32 and a one-ulp correction by two fma
- * residuals (9), wrapped in a 2^32 pre-scale / 2^-16 post-scale for arguments below 2^-96 and a class fix-up (7) -- and a
- * division into 11 -- v_rcp_f32 and six fma / mul (8, 7 with numerator 1), wrapped in v_div_scale x 2 and v_div_fixup.  A
- * quarter of the render kernels' instructions are these expansions.  The wrapping only acts outside a range the renderer
- * never leaves in practice, so the unwrapped sequences are used here, transcribed instruction for instruction, behind a
- * WAVE-UNIFORM guard: if any lane of the wave holds an argument the wrapping would have acted on, the whole wave takes the
- * compiler's sequence (a scalar branch, never taken in practice) -- so the result is the correctly rounded one for EVERY
- * argument, by construction where the wrapping is the identity, by the compiler's code elsewhere.
- *   dm_sqrt: unwrapped for x = +-0, |x| >= 2^-96 (incl. +inf and the negative arguments, NaN either way) and NaN (all of which
- *   leave the unwrapped sequence as they leave the wrapped one); wrapped when 0 < |x| < 2^-96 (the exhaustive test found the
- *   negative denormals: v_sqrt_f32 returns -0 for them where the scaled sequence returns NaN).
- *   dm_rsqrt_sum (norm3: 1 / sqrt(x), two roundings as written): unwrapped for 2^-96 <= x < 2^126, then sqrt(x) lies in
- *   [2^-48, 2^63), where v_div_scale scales nothing and v_div_fixup passes the quotient through.
- * tests/test_gpu_parity.py::test_unwrapped_sqrt_and_reciprocal_over_all_floats compares both with the compiler's own
- * `__builtin_sqrtf(x)` and `1.0f / x` on EVERY binary32 value on the MI355X.  DM_PLAIN_DIVSQRT: the compiler's sequences everywhere (A/B). */
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DM_PLAIN_DIVSQRT)
-DM_HD float dm_sqrt_unwrapped(float x) {
-    float s = __builtin_amdgcn_sqrtf(x);
-    const float sd = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) - 1u), su = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) + 1u);
-    const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
-    s = (0.0f >= rd) ? sd : s;
-    s = (0.0f < ru) ? su : s;
-    return s;
-}
-DM_HD float dm_rcp_unwrapped(float b) {
-    float y = __builtin_amdgcn_rcpf(b);
-    const float e0 = __builtin_fmaf(-b, y, 1.0f);
-    y = __builtin_fmaf(e0, y, y);
-    float q = y;                                  /* 1.0f * y */
-    const float e1 = __builtin_fmaf(-b, q, 1.0f);
-    q = __builtin_fmaf(e1, y, q);
-    const float e2 = __builtin_fmaf(-b, q, 1.0f);
-    return __builtin_fmaf(e2, y, q);
-}
-DM_HD float dm_sqrt(float x) {
-    const bool wrap = __builtin_fabsf(x) < 0x1p-96f && x != 0.0f;   /* 0 < |x| < 2^-96 (a negative denormal: v_sqrt_f32 gives -0, the scaled sequence NaN) */
-    if (__builtin_amdgcn_ballot_w64(wrap) != 0ULL) return __builtin_sqrtf(x);
-    return dm_sqrt_unwrapped(x);
-}
-DM_HD float dm_rsqrt_sum(float x) {   /* 1.0f / dm_sqrt(x) */
-    const bool plain = x >= 0x1p-96f && x < 0x1p126f;
-    if (__builtin_amdgcn_ballot_w64(!plain) != 0ULL) return 1.0f / __builtin_sqrtf(x);
-    return dm_rcp_unwrapped(dm_sqrt_unwrapped(x));
-}
-#else
 DM_HD float dm_sqrt(float x) { return __builtin_sqrtf(x); }
-DM_HD float dm_rsqrt_sum(float x) { return 1.0f / __builtin_sqrtf(x); }
-#endif
 DM_HD float dm_rint(float x) { return __builtin_rintf(x); }
 /* min/max with the semantics of llvm.minnum/maxnum as gfx950 executes them (v_min_f32 /
  * v_max_f32, IEEE mode): a NaN operand is ignored, and -0 orders below +0.  On the device this

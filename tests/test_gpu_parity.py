@@ -182,17 +182,6 @@ def half_conversion_cases():
     return codes, ref32, words, ref16
 
 
-def test_unwrapped_sqrt_and_reciprocal_over_all_floats():
-    """include/vrt_detmath.h spells the device's sqrt and 1 / sqrt as the compiler's correctly rounded sequences WITHOUT their range
-    scaling, behind a wave-uniform guard that sends a wave with an out-of-range argument through the compiler's own code.  On the
-    MI355X, for EVERY one of the 2^32 binary32 bit patterns: the guarded forms equal `__builtin_sqrtf(x)` / `1.0f / __builtin_sqrtf(x)`
-    bit for bit, and the unwrapped sequences alone equal them (and `1.0f / x`) on the whole domain the guards let through."""
-    import ctypes as C
-    out = (C.c_uint64 * 8)()
-    assert _lib.load().vrt_divsqrt_selftest(0, out) == 0
-    assert list(out[:4]) == [0, 0, 0, 0], [f"check {k}: {out[k]} mismatches, e.g. pattern {out[4 + k]:#010x}" for k in range(4) if out[k]]
-
-
 def test_half_conversions_on_device_equal_host_definition():
     """dm_f32_to_f16 / dm_f16_to_f32 are hardware conversions on the device and bit manipulation on the host
     (include/vrt_detmath.h).  tests/test_detmath.py pins the numpy references used here to the host definition."""

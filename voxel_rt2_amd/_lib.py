@@ -90,8 +90,6 @@ def load(build_if_missing=True):
     lib.vrt_reserve_cus.argtypes = [C.c_void_p, C.c_int]
     lib.vrt_reset_stats.restype = C.c_int
     lib.vrt_reset_stats.argtypes = [C.c_void_p]
-    lib.vrt_divsqrt_selftest.restype = C.c_int
-    lib.vrt_divsqrt_selftest.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
     lib.vrt_detmath_probe.restype = C.c_int
     lib.vrt_detmath_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib

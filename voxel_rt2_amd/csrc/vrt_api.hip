@@ -1177,19 +1177,4 @@ int vrt_detmath_probe(int device, int op, int n, const float* a, const float* b,
     return VRT_OK;
 }
 
-// Every binary32 value through dm_sqrt / dm_rsqrt_sum and their unwrapped cores (vrt_detmath.h) against the compiler's correctly
-// rounded sqrt and division: out[0..3] = mismatches per check, out[4..7] = a mismatching bit pattern (k_divsqrt_selftest).
-int vrt_divsqrt_selftest(int device, uint64_t* out8) {
-    if (!out8) return fail(VRT_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(device));
-    unsigned long long* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(d, 0, 8 * sizeof(unsigned long long)));
-    HIP_TRY(launch_divsqrt_selftest(0, d));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out8, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    hipFree(d);
-    return VRT_OK;
-}
-
 }  // extern "C"

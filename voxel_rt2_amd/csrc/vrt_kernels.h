@@ -58,7 +58,6 @@ hipError_t launch_tonemap(hipStream_t st, const FrameParams& fp, const f3* hdr, 
 hipError_t launch_tonemap8(hipStream_t st, const FrameParams& fp, const f3* hdr, uint32_t* ldr8 /* rgba, 8 bits each */, int r0, int r1);
 hipError_t launch_diag_read(hipStream_t st, unsigned long long* out, int reset);  // -DVRT_DIAG_REGIONS builds only
 hipError_t launch_detmath_probe(hipStream_t st, int op, int n, const float* a, const float* b, float* out);
-hipError_t launch_divsqrt_selftest(hipStream_t st, unsigned long long* out /* [8], zeroed */);   // every binary32 pattern: vrt_detmath.h's unwrapped sequences
 
 // sky precompute (vrt_sky_kernels.hip)
 struct SkyPrecompute {

@@ -757,43 +757,6 @@ __global__ void k_detmath_probe(int op, int n, const float* a, const float* b, f
     out[i] = r;
 }
 
-// Every binary32 bit pattern through the unwrapped sqrt / reciprocal sequences of vrt_detmath.h and through the compiler's own:
-// out[k] = mismatches of check k, out[4 + k] = one mismatching pattern.  Checks: 0 dm_sqrt (guarded) against __builtin_sqrtf on
-// every pattern; 1 the unwrapped sqrt alone on its domain (everything but 0 < |x| < 2^-96); 2 dm_rsqrt_sum (guarded) against
-// 1.0f / __builtin_sqrtf on every pattern; 3 the unwrapped reciprocal alone against 1.0f / b for 2^-96 <= |b| < 2^126.
-__global__ __launch_bounds__(256) void k_divsqrt_selftest(unsigned long long* out) {
-    unsigned long long bad[4] = {0ULL, 0ULL, 0ULL, 0ULL};
-    uint32_t first[4] = {0u, 0u, 0u, 0u};
-    const uint32_t stride = gridDim.x * blockDim.x;   // a power of two: every thread makes the same number of trips
-    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    for (unsigned long long k = 0; k < (1ULL << 32) / stride; k++, u += stride) {
-        const float x = dm_u2f(u);
-        const float ref_s = __builtin_sqrtf(x), ref_r = 1.0f / __builtin_sqrtf(x), ref_q = 1.0f / x;
-        float got[4];
-        bool in[4];
-        got[0] = dm_sqrt(x); in[0] = true;
-        got[2] = dm_rsqrt_sum(x); in[2] = true;
-#if defined(DM_PLAIN_DIVSQRT) || !defined(__HIP_DEVICE_COMPILE__)   // (the host pass only parses this)
-        got[1] = ref_s; in[1] = false; got[3] = ref_q; in[3] = false;
-#else
-        got[1] = dm_sqrt_unwrapped(x); in[1] = !(dm_abs(x) < 0x1p-96f && x != 0.0f);
-        got[3] = dm_rcp_unwrapped(x); in[3] = dm_abs(x) >= 0x1p-96f && dm_abs(x) < 0x1p126f;
-#endif
-        const float want[4] = {ref_s, ref_s, ref_r, ref_q};
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-            if (in[c] && dm_f2u(got[c]) != dm_f2u(want[c])) { bad[c]++; first[c] = u; }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; c++)
-        if (bad[c]) { atomicAdd(&out[c], bad[c]); out[4 + c] = first[c]; }
-}
-hipError_t launch_divsqrt_selftest(hipStream_t st, unsigned long long* out) {
-    hipLaunchKernelGGL(k_divsqrt_selftest, dim3(4096), dim3(256), 0, st, out);
-    hipError_t e_ = hipGetLastError();
-    return e_;
-}
-
 // ---- host-side launchers -----------------------------------------------------------------------
 #define VRT_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 

@@ -46,7 +46,7 @@ VRT_DEV float comp(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 VRT_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 VRT_DEV f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 VRT_DEV float len3(f3 a) { return dm_sqrt(dot3(a, a)); }
-VRT_DEV f3 norm3(f3 a) { float inv = dm_rsqrt_sum(dot3(a, a)); return inv * a; }   // = 1.0f / len3(a), see dm_rsqrt_sum
+VRT_DEV f3 norm3(f3 a) { float inv = 1.0f / len3(a); return inv * a; }
 VRT_DEV f3 abs3(f3 a) { return mk3(dm_abs(a.x), dm_abs(a.y), dm_abs(a.z)); }
 VRT_DEV f3 floor3(f3 a) { return mk3(dm_floor(a.x), dm_floor(a.y), dm_floor(a.z)); }
 VRT_DEV f3 clamp3(f3 a, float lo, float hi) { return mk3(dm_clamp(a.x, lo, hi), dm_clamp(a.y, lo, hi), dm_clamp(a.z, lo, hi)); }
