@@ -329,6 +329,7 @@ def test_scene_api_end_to_end(tmp_path, monkeypatch):
     monkeypatch.setenv("VRT_SEED", "4")
     monkeypatch.setenv("VRT_SKY_RES", "0")
     monkeypatch.setenv("VRT_OUT", str(tmp_path / "out.png"))
+    monkeypatch.setenv("VRT_PRESENT", "1")   # every frame's 8-bit image copied to the host, a frame behind (scene.py:255-262's loop)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     monkeypatch.syspath_prepend(root)
     sys.modules.pop("scene", None)
@@ -352,6 +353,8 @@ def test_scene_api_end_to_end(tmp_path, monkeypatch):
     img = sc.finish()
     assert (tmp_path / "out.png").exists() and img.shape == (96, 160, 4)
     assert np.isfinite(img).all() and img[..., :3].std() > 0.02
+    # the last frame presented asynchronously (rgba8) is the 8-bit form of the image fetched at the end
+    assert np.array_equal(sc.presented, (np.clip(img, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8))
     # same state through the oracle
     r = sc.renderer
     cfg = host.make_config(160, 96, voxel_edges=0.05, exposure=2.0, max_depth=5, seed=4)

@@ -870,7 +870,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
                 int g0 = c->own0 - 2 < c->buf0 ? c->buf0 : c->own0 - 2, g1 = c->own1 + 2 > c->buf1 ? c->buf1 : c->own1 + 2;
                 if (record(c, 2, &a, &b) != VRT_OK) return VRT_E_DEVICE;
                 HIP_TRY(hipEventRecord(a, c->stream));
-                HIP_TRY(launch_gris(c->stream, c->cfg.grid_res, instr, fps, sc, gb, g0, g1, s > 0));   // (s > 0: same g-buffer, same camera as pass s - 1)
+                HIP_TRY(launch_gris(c->stream, c->cfg.grid_res, instr, fps, sc, gb, g0, g1));
                 HIP_TRY(hipEventRecord(b, c->stream));
                 cd = c->d_color_d2;
                 cs = c->d_color_s2;

@@ -52,8 +52,7 @@ hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool in
                               bool dense);                      // ... whose SHADE walks its shadow rays with the branchy descent (dense grids)
 hipError_t launch_mat_derived(hipStream_t st, const float* mats, float* mats_x /*[128][8]*/);  // after every material upload
 // spatial reuse over rows [r0, r1); first a per-pixel prepare pass over all rows the launch holds (fp.row0..fp.row1) into gb.geo / gb.src
-hipError_t launch_gris(hipStream_t st, int grid_res, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1,
-                       bool same_gbuffer /* a later sample of the same fused render launch: the GrisGeo records of the last pass still hold */);
+hipError_t launch_gris(hipStream_t st, int grid_res, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1);
 hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1, int n_samples);
 hipError_t launch_tonemap(hipStream_t st, const FrameParams& fp, const f3* hdr, f4* ldr, int r0, int r1);
 hipError_t launch_tonemap8(hipStream_t st, const FrameParams& fp, const f3* hdr, uint32_t* ldr8 /* rgba, 8 bits each */, int r0, int r1);

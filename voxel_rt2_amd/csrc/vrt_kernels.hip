@@ -678,11 +678,10 @@ __global__ __launch_bounds__(256, (PHASE == 1 ? VRT_GRIS_MIN_WAVES_A : PHASE == 
 }
 
 // once per pixel of every row the launch holds: the records k_gris reads ~32 times per pixel (vrt_restir.h)
-template <bool GEO>
 __global__ __launch_bounds__(256) void k_gris_prepare(FrameParams fp, SceneData sc, GrisBuffers gb) {
     const int u = blockIdx.x * 64 + (threadIdx.x & 63);
     const int v = fp.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (u < fp.W && v < fp.row1) gris_prepare_pixel<GEO>(fp, sc, gb, u, v);
+    if (u < fp.W && v < fp.row1) gris_prepare_pixel(fp, sc, gb, u, v);
 }
 __global__ void k_mat_derived(const float* mats, float* mats_x) {
     const int id = threadIdx.x;
@@ -851,10 +850,8 @@ hipError_t launch_mat_derived(hipStream_t st, const float* mats, float* mats_x) 
     VRT_LAUNCH_CHECK();
     return hipSuccess;
 }
-hipError_t launch_gris(hipStream_t st, int grid_res, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1, bool same_gbuffer) {
-    // same_gbuffer: the g-buffer is the one the last pass prepared its GrisGeo records from (a later sample of one fused render launch)
-    if (same_gbuffer) hipLaunchKernelGGL(k_gris_prepare<false>, dim3((fp.W + 63) / 64, (fp.row1 - fp.row0 + 3) / 4), dim3(256), 0, st, fp, sc, gb);
-    else hipLaunchKernelGGL(k_gris_prepare<true>, dim3((fp.W + 63) / 64, (fp.row1 - fp.row0 + 3) / 4), dim3(256), 0, st, fp, sc, gb);
+hipError_t launch_gris(hipStream_t st, int grid_res, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1) {
+    hipLaunchKernelGGL(k_gris_prepare, dim3((fp.W + 63) / 64, (fp.row1 - fp.row0 + 3) / 4), dim3(256), 0, st, fp, sc, gb);
     // the tap angles of a pixel are hashed from its 8x8 tile in FRAME coordinates (pathtracer.py:834-836) and worked out once
     // per wave: the wave tiles have to sit on that grid, so the launch starts at the multiple of 8 at or below r0
     const int ra = r0 & ~7;

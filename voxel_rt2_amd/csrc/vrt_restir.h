@@ -287,39 +287,32 @@ struct GrisBuffers {
     ReservoirRec* res_out;
 };
 
-// once per pixel of every row the launch holds (the rows it renders and their halo).  GEO: the pixel as the destination of a shift
-// (GrisGeo) -- a function of the g-buffer alone, which the samples fused into one render launch share (sample 0 writes it), so the
-// passes of a launch's later samples skip it (GEO = false) and only refresh M, the one field that comes from the sample's reservoir.
-template <bool GEO = true>
+// once per pixel of every row the launch holds (the rows it renders and their halo)
 VRT_DEV void gris_prepare_pixel(const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int u, int v) {
     const int idx = (v - fp.row0) * fp.W + u;
+    GrisGeo g;
+    g.n = oct_decode(gb.gb_normal[idx]);
+    g.x1 = xform(fp.view_inv, screen_to_view(pixel_texcoord(fp, (float)u, (float)v), gb.gb_depth[idx], fp.proj_inv), 1.0f);
+    g.dist = len3(g.x1 - fp.camera_pos);
+    g.mat = gb.gb_mat[idx];
+    g.v = norm3(fp.camera_pos - g.x1);
     Reservoir r;
     reservoir_init(r);
     reservoir_decode(r, gb.res_in[idx]);
+    g.M = r.M;
     f3 tx;
-    if constexpr (GEO) {
-        GrisGeo g;
-        g.n = oct_decode(gb.gb_normal[idx]);
-        g.x1 = xform(fp.view_inv, screen_to_view(pixel_texcoord(fp, (float)u, (float)v), gb.gb_depth[idx], fp.proj_inv), 1.0f);
-        g.dist = len3(g.x1 - fp.camera_pos);
-        g.mat = gb.gb_mat[idx];
-        g.v = norm3(fp.camera_pos - g.x1);
-        g.M = r.M;
-        ortho_basis(g.n, tx, g.ty);
-        g.pad = 0u;
-        {   // the pixel's own shading point as every neighbour's shift will set it up (gris_pixel, first tap loop)
-            int id;
-            const Material m = material_from_bits(sc.mats, g.mat, id);
-            Surf ds;
-            surf_set(ds, m, load_mat_derived(gb.mats_x, id), g.n, g.v, cross3(g.n, g.ty), g.ty);
-            const SurfShared c = surf_shared(ds, true, true, true);
-            g.base = m.base; g.fv = c.fv; g.lambert = c.lambert; g.g_v = c.g_v; g.sheen_col = c.sheen_col; g.gc_v = c.gc_v;
-            g.spec_col = c.spec_col; g.pad3 = 0u;
-        }
-        gb.geo[idx] = g;
-    } else {
-        gb.geo[idx].M = r.M;
+    ortho_basis(g.n, tx, g.ty);
+    g.pad = 0u;
+    {   // the pixel's own shading point as every neighbour's shift will set it up (gris_pixel, first tap loop)
+        int id;
+        const Material m = material_from_bits(sc.mats, g.mat, id);
+        Surf ds;
+        surf_set(ds, m, load_mat_derived(gb.mats_x, id), g.n, g.v, cross3(g.n, g.ty), g.ty);
+        const SurfShared c = surf_shared(ds, true, true, true);
+        g.base = m.base; g.fv = c.fv; g.lambert = c.lambert; g.g_v = c.g_v; g.sheen_col = c.sheen_col; g.gc_v = c.gc_v;
+        g.spec_col = c.spec_col; g.pad3 = 0u;
     }
+    gb.geo[idx] = g;
     GrisSrc s;
     s.F = r.z.F; s.M = r.M; s.rc_pos = r.z.rc_pos; s.weight = r.weight; s.rc_normal = r.z.rc_normal; s.jac = r.z.jac;
     s.rc_incident_dir = r.z.rc_incident_dir; s.lobes = r.z.lobes; s.rc_incident_L = r.z.rc_incident_L;
