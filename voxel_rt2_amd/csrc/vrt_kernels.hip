@@ -342,11 +342,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
     __shared__ uint32_t s_fine_base[BIG ? 1 : 512];
     __shared__ float s_mats[128 * 14];
     __shared__ float s_cull[8];
-#ifndef VRT_POOL_GLOBAL
-#define VRT_POOL_GLOBAL 0   // A/B: the path records in a per-wave stretch of global memory (L2) instead of LDS, which is what limits
-                            // a pool to 128 slots; see profiles/README.md
-#endif
-    __shared__ uint32_t s_pool[VRT_POOL_GLOBAL ? 1 : WAVES][VRT_POOL_GLOBAL ? 1 : PF_COUNT * VRT_POOL_SLOTS];
+    __shared__ uint32_t s_pool[WAVES][PF_COUNT * VRT_POOL_SLOTS];
     __shared__ uint32_t s_state[WAVES][VRT_POOL_WORDS * 64];
     __shared__ uint32_t s_list[WAVES][VRT_POOL_SLOTS];
     LdsPyramid2<G, CULL, SHBR> P;
@@ -375,9 +371,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
     if (blockIdx.x == 0 && threadIdx.x < VRT_WORK_HEADS) next_counter[threadIdx.x * VRT_WORK_HEAD_STRIDE] = 0u;  // the next launch's heads (idle during this launch)
     if (blockIdx.x == 0 && threadIdx.x == 0) next_counter[1] = 0u;  // and its "drain announced" word
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int COLD_ = ColdLine<RESTIR>::count;
-    uint32_t* const pool = VRT_POOL_GLOBAL ? cold + (size_t)gridDim.x * WAVES * VRT_POOL_SLOTS * COLD_ + (size_t)(blockIdx.x * WAVES + wave) * (PF_COUNT * VRT_POOL_SLOTS)
-                                           : s_pool[VRT_POOL_GLOBAL ? 0 : wave];
+    uint32_t* const pool = s_pool[wave];
     uint32_t* const state = s_state[wave];
     uint32_t* const list = s_list[wave];
     for (int k = 0; k < VRT_POOL_WORDS; k++) state[k * 64 + lane] = (k * 64 + lane < VRT_POOL_SLOTS) ? (uint32_t)SLOT_EMPTY : 4u;
@@ -826,7 +820,7 @@ hipError_t query_render_pool_residency(int grid_res, bool restir, bool instr, in
     return e;
 }
 size_t pool_scratch_bytes(int grid_res, bool restir, int n_blocks) {
-    return (size_t)n_blocks * pool_waves_per_block(grid_res) * VRT_POOL_SLOTS * ((restir ? ColdLine<true>::count : ColdLine<false>::count) + (VRT_POOL_GLOBAL ? (int)PF_COUNT : 0)) * sizeof(uint32_t);
+    return (size_t)n_blocks * pool_waves_per_block(grid_res) * VRT_POOL_SLOTS * (restir ? ColdLine<true>::count : ColdLine<false>::count) * sizeof(uint32_t);
 }
 hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                               const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold,
