@@ -154,7 +154,7 @@ int vrt_fetch_hdr_device_async(vrt_ctx* ctx, void* device_ptr);
  * so that rendering, the tile copy and a following RCCL collective are ordered on the device without host
  * round trips; NULL returns to a private stream.  The stream must outlive the context or be reset first.
  * Everything a caller can observe (results, fetches, stats) is ordered on this stream.  Render launches of
- * consecutive vrt_accumulate calls may run on two internal streams of the context so that one starts while the
+ * consecutive vrt_accumulate calls may run on two to eight internal streams of the context so that one starts while the
  * previous one drains; each is followed, on THIS stream, by the temporal pass that waits for it. */
 int vrt_set_stream(vrt_ctx* ctx, void* hip_stream);
 /* Renderer.fetch_image (pathtracer.py:1321-1323, 634-662): LDR rgba f32[H][W][4] */

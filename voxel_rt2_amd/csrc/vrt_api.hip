@@ -99,7 +99,7 @@ struct vrt_ctx {
     f3* alt_multi_d[VRT_MAX_SETS - 1] = {}; f3* alt_spec_planes[VRT_MAX_SETS - 1] = {}; float* alt_refl_planes[VRT_MAX_SETS - 1] = {};
     f3* alt_gb_pos[VRT_MAX_SETS - 1] = {}; uint32_t* alt_gb_mat[VRT_MAX_SETS - 1] = {};
     uint32_t* alt_pool_scratch[VRT_MAX_STREAMS - 1] = {};  // the other render streams' scratch
-    int n_streams = 2;   // depth of the launch pipeline (ensure_overlap): 2, or 4 with launches of half the workgroups each
+    int n_streams = 2;   // depth of the launch pipeline (ensure_overlap): 2, 4 with launches of half the workgroup slots each, or 8 with quarters
     int grid_div = 1;    // an overlapped launch takes render_blocks / grid_div workgroups
     // A render launch queued behind another on another render stream would be dispatched at once and sit in the
     // queue until workgroups retire -- which the profiler and the events count as its run time.  Instead the kernel
