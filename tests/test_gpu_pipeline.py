@@ -312,13 +312,14 @@ def test_rccl_beside_the_library():
         stream = torch.cuda.Stream()
         b.set_stream(stream.cuda_stream)
         parallel.configure_session(b, 2)   # as a rank of a larger group would
-        tile = torch.zeros((270, 480, 3), dtype=torch.float32, device="cuda")
-        got = [torch.zeros_like(tile)]
-        for _ in range(3):
+        ring = [torch.zeros((270, 480, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+        b.set_hdr_targets([t.data_ptr() for t in ring])   # the temporal pass writes the tile the gather reads (bench.py's hand-over)
+        got = [torch.zeros_like(ring[0])]
+        for k in range(3):
             with torch.cuda.stream(stream):
                 b.accumulate(4)
-                b.fetch_hdr_device_async(tile.data_ptr())
-                dist.gather(tile, got, dst=0)
+                assert b.hdr_targets_written() == k + 1
+                dist.gather(ring[k % 2], got, dst=0)
                 t = torch.ones(8, device="cuda"); dist.all_reduce(t)
         stream.synchronize(); torch.cuda.synchronize()
         same = bool(np.array_equal(got[0].cpu().numpy().view(np.uint32), want.view(np.uint32)))
