@@ -319,7 +319,7 @@ def test_rccl_beside_the_library():
             with torch.cuda.stream(stream):
                 b.accumulate(4)
                 assert b.hdr_targets_written() == k + 1
-                dist.gather(ring[k % 2], got, dst=0)
+                dist.gather(ring[k & 1], got, dst=0)
                 t = torch.ones(8, device="cuda"); dist.all_reduce(t)
         stream.synchronize(); torch.cuda.synchronize()
         same = bool(np.array_equal(got[0].cpu().numpy().view(np.uint32), want.view(np.uint32)))
