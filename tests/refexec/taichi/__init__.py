@@ -68,6 +68,91 @@ def _is_float(x):
     return isinstance(x, (_b.float, _np.floating))
 
 
+# ---- scalar arithmetic: Taichi's type promotion, not numpy's ---------------------------------------------------------------
+# (numpy would compute float32 * int32 in float64; Taichi converts the integer to f32 and multiplies in f32.)  Python numbers
+# are compile-time constants: they take the type of the typed operand they meet (a float constant beside an integer value makes
+# both default_fp = f32); two Python numbers stay Python numbers.
+_FLOATS = (_np.float16, _np.float32, _np.float64)
+
+
+def _rank(t):
+    return (2 if issubclass(t, _np.floating) else 1 if issubclass(t, _np.unsignedinteger) else 0, _np.dtype(t).itemsize)
+
+
+def _promote(a, c):
+    ta, tc = type(a), type(c)
+    wa, wc = not isinstance(a, _np.generic), not isinstance(c, _np.generic)
+    if wa and wc:
+        return None
+    if wa or wc:
+        w, st = (a, tc) if wa else (c, ta)
+        if st is _np.bool_:
+            st = _np.int32
+        if isinstance(w, _b.float) and not issubclass(st, _np.floating):
+            return _np.float32
+        return st
+    if ta is _np.bool_:
+        ta = _np.int32
+    if tc is _np.bool_:
+        tc = _np.int32
+    if ta is tc:
+        return ta
+    fa, fc = issubclass(ta, _np.floating), issubclass(tc, _np.floating)
+    if fa != fc:
+        return ta if fa else tc
+    sa, sc = _np.dtype(ta).itemsize, _np.dtype(tc).itemsize
+    if sa != sc:
+        return ta if sa > sc else tc
+    return ta if issubclass(ta, _np.unsignedinteger) else tc
+
+
+def _conv(x, t):
+    if type(x) is t:
+        return x
+    if issubclass(t, _np.floating):
+        return t(x)
+    if isinstance(x, (_b.float, _np.floating)):
+        return _cast1(x, t)
+    return _np.int64(_b.int(x) & 0xFFFFFFFFFFFFFFFF if _b.int(x) >= 2**63 else _b.int(x)).astype(t) if -2**63 <= _b.int(x) < 2**64 else t(0)
+
+
+_PYOPS = {"add": lambda a, c: a + c, "sub": lambda a, c: a - c, "mul": lambda a, c: a * c, "truediv": lambda a, c: a / c,
+          "floordiv": lambda a, c: a // c, "mod": lambda a, c: a % c, "pow": lambda a, c: a ** c, "lshift": lambda a, c: a << c,
+          "rshift": lambda a, c: a >> c, "and": lambda a, c: a & c, "or": lambda a, c: a | c, "xor": lambda a, c: a ^ c}
+
+
+def _sbin(op, a, c):
+    """One scalar operation."""
+    if isinstance(a, _b.bool):
+        a = _b.int(a)
+    if isinstance(c, _b.bool):
+        c = _b.int(c)
+    if op == "pow":
+        return _pow(a, c)
+    t = _promote(a, c)
+    if t is None:
+        return _PYOPS[op](a, c)
+    if op == "truediv" and not issubclass(t, _np.floating):
+        t = _np.float32
+    if t is _np.float64:
+        t = _np.float32
+    if t is _np.int64:
+        t = _np.int32
+    if op in ("lshift", "rshift") and not isinstance(a, _np.generic):
+        t = _np.int32 if not isinstance(c, _np.unsignedinteger) else type(c)   # 1 << n: the constant is an i32
+    return _PYOPS[op](_conv(a, t), _conv(c, t))
+
+
+def _binop(op, a, c):
+    """`a op c` inside a ti.func / ti.kernel (the AST pass routes every binary operator here)."""
+    if isinstance(a, (Vector, Matrix)) or isinstance(c, (Vector, Matrix)):
+        return _PYOPS[op](a, c) if op != "matmul" else a @ c
+    if isinstance(a, (_b.int, _b.float, _np.generic)) and isinstance(c, (_b.int, _b.float, _np.generic)):
+        return _sbin(op, a, c)
+    return _PYOPS[op](a, c)    # lists, strings, ... outside the DSL's value types
+
+
+
 class Vector:
     __slots__ = ("_v",)
     __hash__ = None
@@ -138,23 +223,25 @@ class Vector:
             return Vector._new([_norm(fn(c, a)) for a, c in zip(self._v, ov)])
         return Vector._new([_norm(fn(a, c)) for a, c in zip(self._v, ov)])
 
-    def __add__(self, o): return self._bin(o, lambda a, c: a + c)
-    def __radd__(self, o): return self._bin(o, lambda a, c: a + c, True)
-    def __sub__(self, o): return self._bin(o, lambda a, c: a - c)
-    def __rsub__(self, o): return self._bin(o, lambda a, c: a - c, True)
-    def __mul__(self, o): return self._bin(o, lambda a, c: a * c)
-    def __rmul__(self, o): return self._bin(o, lambda a, c: a * c, True)
-    def __truediv__(self, o): return self._bin(o, _div)
-    def __rtruediv__(self, o): return self._bin(o, _div, True)
+    def __add__(self, o): return self._bin(o, lambda a, c: _sbin("add", a, c))
+    def __radd__(self, o): return self._bin(o, lambda a, c: _sbin("add", a, c), True)
+    def __sub__(self, o): return self._bin(o, lambda a, c: _sbin("sub", a, c))
+    def __rsub__(self, o): return self._bin(o, lambda a, c: _sbin("sub", a, c), True)
+    def __mul__(self, o): return self._bin(o, lambda a, c: _sbin("mul", a, c))
+    def __rmul__(self, o): return self._bin(o, lambda a, c: _sbin("mul", a, c), True)
+    def __truediv__(self, o): return self._bin(o, lambda a, c: _sbin("truediv", a, c))
+    def __rtruediv__(self, o): return self._bin(o, lambda a, c: _sbin("truediv", a, c), True)
     def __pow__(self, o): return self._bin(o, _pow)
     def __rpow__(self, o): return self._bin(o, _pow, True)
-    def __lshift__(self, o): return self._bin(o, lambda a, c: a << c)
-    def __rshift__(self, o): return self._bin(o, lambda a, c: a >> c)
-    def __rrshift__(self, o): return self._bin(o, lambda a, c: a >> c, True)
-    def __rlshift__(self, o): return self._bin(o, lambda a, c: a << c, True)
-    def __and__(self, o): return self._bin(o, lambda a, c: a & c)
-    def __or__(self, o): return self._bin(o, lambda a, c: a | c)
-    def __xor__(self, o): return self._bin(o, lambda a, c: a ^ c)
+    def __lshift__(self, o): return self._bin(o, lambda a, c: _sbin("lshift", a, c))
+    def __rshift__(self, o): return self._bin(o, lambda a, c: _sbin("rshift", a, c))
+    def __rrshift__(self, o): return self._bin(o, lambda a, c: _sbin("rshift", a, c), True)
+    def __rlshift__(self, o): return self._bin(o, lambda a, c: _sbin("lshift", a, c), True)
+    def __and__(self, o): return self._bin(o, lambda a, c: _sbin("and", a, c))
+    def __or__(self, o): return self._bin(o, lambda a, c: _sbin("or", a, c))
+    def __xor__(self, o): return self._bin(o, lambda a, c: _sbin("xor", a, c))
+    def __mod__(self, o): return self._bin(o, lambda a, c: _sbin("mod", a, c))
+    def __floordiv__(self, o): return self._bin(o, lambda a, c: _sbin("floordiv", a, c))
     def __neg__(self): return Vector._new([-a for a in self._v])
     def __pos__(self): return self
     def __abs__(self): return Vector._new([_b.abs(a) for a in self._v])
@@ -167,23 +254,23 @@ class Vector:
 
     def dot(self, o):
         ov = o._v if isinstance(o, Vector) else [_typed(x) for x in o]
-        acc = _norm(self._v[0] * ov[0])
+        acc = _sbin("mul", self._v[0], ov[0])
         for a, c in zip(self._v[1:], ov[1:]):
-            acc = _norm(acc + _norm(a * c))
+            acc = _sbin("add", acc, _sbin("mul", a, c))
         return acc
     def norm_sqr(self): return self.dot(self)
     def norm(self): return sqrt(self.norm_sqr())
     def normalized(self, eps=0):
-        inv = _div(1.0, self.norm() + eps) if eps else _div(1.0, self.norm())
+        inv = _sbin("truediv", 1.0, _sbin("add", self.norm(), eps)) if eps else _sbin("truediv", 1.0, self.norm())
         return self * inv
     def cross(self, o):
         a, c = self._v, (o._v if isinstance(o, Vector) else [_typed(x) for x in o])
-        return Vector._new([_norm(_norm(a[1] * c[2]) - _norm(a[2] * c[1])), _norm(_norm(a[2] * c[0]) - _norm(a[0] * c[2])),
-                            _norm(_norm(a[0] * c[1]) - _norm(a[1] * c[0]))])
+        m, sub = (lambda p, q: _sbin("mul", p, q)), (lambda p, q: _sbin("sub", p, q))
+        return Vector._new([sub(m(a[1], c[2]), m(a[2], c[1])), sub(m(a[2], c[0]), m(a[0], c[2])), sub(m(a[0], c[1]), m(a[1], c[0]))])
     def sum(self):
         acc = self._v[0]
         for a in self._v[1:]:
-            acc = _norm(acc + a)
+            acc = _sbin("add", acc, a)
         return acc
     def max(self): return _b.max(self._v)
     def min(self): return _b.min(self._v)
@@ -196,8 +283,8 @@ class Matrix:
     """Row-major small matrix; Matrix(rows) with rows = Vectors (ti.math.mat3(a, b, c) stacks its arguments as rows)."""
     __hash__ = None
 
-    def __init__(self, rows):
-        self.rows = [r._copy() if isinstance(r, Vector) else Vector(r) for r in rows]
+    def __init__(self, rows, dt=None):
+        self.rows = [r._copy() if isinstance(r, Vector) else Vector(r, dt) for r in rows]
 
     def _copy(self): return Matrix(self.rows)
     def transpose(self):
@@ -353,6 +440,13 @@ def random(dtype=float):
 
 
 # ---- fields -------------------------------------------------------------------------------------------------------------
+_oob_reads = ["error"]
+
+
+def set_out_of_bounds_reads(policy):
+    _oob_reads[0] = policy
+
+
 class _Axes:
     def __init__(self, names): self.names = names
 
@@ -410,6 +504,14 @@ class _FieldBase:
         k = _idx_tuple(idx)
         return tuple(a - o for a, o in zip(k, self.offset)) if any(self.offset) else k
 
+    def _read_key(self, idx):
+        """Reads outside a multi-dimensional field are undefined in release-mode Taichi; the caller picks what they see:
+        the nearest element ("clamp") or an error (default)."""
+        k = self._key(idx)
+        if _oob_reads[0] == "clamp" and len(k) > 1:
+            k = tuple(_b.min(_b.max(a, 0), n - 1) for a, n in zip(k, self.shape))
+        return k
+
     def _indices(self):
         for idx in _it.product(*[range(o, o + n) for n, o in zip(self.shape, self.offset)]):
             _loop_index[0] = idx
@@ -433,7 +535,7 @@ class _Field(_FieldBase):
     def _alloc(self): self.a = _np.zeros(self.shape, dtype=self.dtype)
 
     def __getitem__(self, idx):
-        k = self._key(idx)
+        k = self._read_key(idx)
         if len(k) == 1 and self.a.ndim == 1 and not 0 <= k[0] < self.a.shape[0]:
             return self.dtype(0)          # past the end: release-mode Taichi does not check; unwritten memory reads as zero here
         return self.a[k]
@@ -477,7 +579,7 @@ class _VectorField(_FieldBase):
     def _alloc(self): self.a = _np.zeros(self.shape + (self.n,), dtype=self.dtype)
 
     def __getitem__(self, idx):
-        k = self._key(idx)
+        k = self._read_key(idx)
         v = object.__new__(_BoundVector)
         object.__setattr__(v, "_v", [self.dtype(x) for x in self.a[k]])
         object.__setattr__(v, "_f", self)
@@ -502,7 +604,7 @@ class _ObjectField(_FieldBase):
     def _alloc(self): self.objs = {}
 
     def __getitem__(self, idx):
-        k = self._key(idx)
+        k = self._read_key(idx)
         o = self.objs.get(k)
         if o is None:
             o = self.objs[k] = self._make()
@@ -682,8 +784,13 @@ class _Scoping(_ast.NodeTransformer):
         self.generic_visit(node)
         if isinstance(node.target, _ast.Name):
             load = _ast.Name(id=node.target.id, ctx=_ast.Load())
-            return _ast.Assign(targets=[node.target], value=_call("__ti_assign", [load, _ast.BinOp(left=load, op=node.op, right=node.value)]))
-        return node
+            return _ast.Assign(targets=[node.target], value=_call("__ti_assign", [load, _call("__ti_binop", [_ast.Constant(self._OPS[type(node.op)]), load, node.value])]))
+        import copy as _cp
+        tl = _cp.deepcopy(node.target)
+        for sub in _ast.walk(tl):
+            if hasattr(sub, "ctx"):
+                sub.ctx = _ast.Load()
+        return _ast.Assign(targets=[node.target], value=_call("__ti_binop", [_ast.Constant(self._OPS[type(node.op)]), tl, node.value]))
 
     def visit_Expr(self, node):
         self.generic_visit(node)
@@ -698,6 +805,14 @@ class _Scoping(_ast.NodeTransformer):
             vals = _ast.Tuple(elts=[_ast.Name(id=p, ctx=_ast.Load()) for p in self.byref_params], ctx=_ast.Load())
             node.value = _ast.Tuple(elts=[node.value or _ast.Constant(None), vals], ctx=_ast.Load())
         return node
+
+    _OPS = {_ast.Add: "add", _ast.Sub: "sub", _ast.Mult: "mul", _ast.Div: "truediv", _ast.FloorDiv: "floordiv", _ast.Mod: "mod",
+            _ast.Pow: "pow", _ast.LShift: "lshift", _ast.RShift: "rshift", _ast.BitAnd: "and", _ast.BitOr: "or", _ast.BitXor: "xor",
+            _ast.MatMult: "matmul"}
+
+    def visit_BinOp(self, node):
+        self.generic_visit(node)
+        return _call("__ti_binop", [_ast.Constant(self._OPS[type(node.op)]), node.left, node.right])
 
     def visit_Call(self, node):
         self.generic_visit(node)
@@ -773,6 +888,7 @@ def _compile(fn, fdef, byref):
     _ast.fix_missing_locations(tree)
     g = fn.__globals__
     g["__ti_copy"], g["__ti_atomic"], g["__ti_assign"], g["__ti_assign_tuple"], g["__ti_unset"] = _copy, _atomic, _assign, _assign_tuple, _UNSET
+    g["__ti_binop"] = _binop
     # inside kernels the builtins act on typed values / vectors the Taichi way
     for key, v in (("abs", abs), ("max", max), ("min", min), ("pow", pow), ("round", round), ("int", lambda x=0: _cast1(x, _np.int32)),
                    ("float", lambda x=0.0: _cast1(x, _np.float32)), ("all", lambda x: x.all() if isinstance(x, Vector) else _b.all(x)),
