@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/reference/*.npz: outputs of THE REFERENCE'S OWN SOURCE FILES -- test infrastructure, build container only.
+
+The reference (/root/reference/renderer/*.py) is Python that only runs through the Taichi JIT, which is not installed and
+cannot be fetched.  What is possible is to execute the reference's source text, imported from where it
+lies and never copied, under a host-side emulation of the Taichi DSL subset it uses (tests/refexec/taichi: one reading of
+Taichi's semantics -- f32 / i32 defaults and Taichi's type promotion, value semantics, typed locals, ti.template() parameters by
+reference, constant whole-number powers by repeated multiplication, maxnum / minnum, unorm8 textures).  A `ReferenceSession`
+below wraps the reference's `Renderer` in the session interface the oracle, the emulated device code and libvrt_hip.so already
+share (voxel_rt2_amd/_session.py), so the cases of this file are driven through `make_golden.run_case` exactly like theirs.
+
+What the reference leaves undefined is supplied here the way DESIGN.md section 5 records it (and nowhere else):
+  * ti.random(): the build's counter-based streams (include/vrt_detmath.h dm_rng: stream 0 = render, 1 = spatial_GRIS, per pixel
+    and frame; stream 3 = the TAA jitter draw of set_proj_mat), read through the oracle's probe `orc_unit_rng`;
+  * sin / cos / exp / log / pow / acos / atan2: the numeric contract's functions (include/vrt_detmath.h, probe `orc_unit_detmath`;
+    their accuracy is bounded separately by tests/test_detmath.py).  `--libm` uses numpy's instead and reports how far the
+    images move (nothing is written);
+  * reads outside the image: the nearest pixel for bilinear / Catmull-Rom taps, unwritten memory (zero) for spatial_GRIS' g-buffer taps,
+    which its own distance test then rejects (= the build's "taps outside the image are skipped");
+  * `self.current_frame` inside spatial_GRIS: the value at first compile, 0;
+  * the camera matrices' inverses: inverted in float64, rounded once (voxel_rt2_amd/camera.py), as the boundary hands them over.
+What these vectors pin: the oracle (and through it the HIP library) against the reference's source text under those semantics.
+What they cannot pin: Taichi's code generation itself (fast-math reassociation, its own elementary functions).
+
+    python tests/golden/make_reference_vectors.py [case ...]      # from the repo root; ~4 min per case (2 M-voxel Python loops)
+"""
+import ctypes as C
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = "/root/reference"
+OUT = os.path.join(HERE, "reference")
+sys.path[:0] = [os.path.join(ROOT, "tests", "refexec"), REFERENCE, ROOT, os.path.join(ROOT, "tests"), HERE]
+
+import numpy as np  # noqa: E402
+import taichi  # noqa: E402,F401   (tests/refexec/taichi, before anything puts the repo root -- and the product's DSL shim -- first)
+
+from reference_cases import CASES  # noqa: E402
+
+
+_PREPARED = {}
+
+
+class ReferenceSession:
+    """The reference's Renderer (pathtracer.py:27) behind the NativeSession interface."""
+
+    def __init__(self, cfg, libm=False):
+        import taichi as ti
+        import orc
+        assert "refexec" in ti.__file__, "tests/refexec must shadow the product's DSL shim"
+        os.chdir(REFERENCE)      # materials.py:97 and atmos.py:86 open files relative to the working directory
+        import renderer.pathtracer as pt
+        self.ti, self.pt, self.cfg = ti, pt, cfg
+        self.W, self.H = cfg.width, cfg.height
+        assert cfg.grid_res == 128 and cfg.sky_res == 0
+        pt.MAX_RAY_DEPTH = cfg.max_depth            # module constants of the reference (pathtracer.py:15-17), set from outside
+        pt.USE_RESTIR_PT = bool(cfg.use_restir)
+        self.L = orc.lib()
+        self._fptr = orc.fptr
+        if not libm:
+            ti.set_elementary(**{n: self._dm(op) for op, n in enumerate(["sin", "cos", "exp", "log", "pow", "acos", "atan2"])})
+        ti.set_random_source(self._random)
+        self.stream, self.jitter_index, self._cache = 3, 0, {}
+        r = self.r = pt.Renderer(dx=cfg.dx, image_res=(self.W, self.H), up=(0, 1, 0), voxel_edges=cfg.voxel_edges, exposure=cfg.exposure)
+        # reads outside the image are undefined in the reference; DESIGN.md section 5: bilinear / Catmull-Rom taps see the nearest
+        # pixel, spatial_GRIS taps outside the image are skipped -- which is what the reference's own distance test (:912) does to a
+        # tap whose g-buffer reads as memory nobody wrote (depth 0 = the near plane, 0.01 from the camera)
+        ti.set_out_of_bounds_reads("clamp", r.color_buffer, r.color_buffer_specular, r.history_buffer, r.history_buffer_specular,
+                                   r.history_buffer_specular_depth, r.gbuff_prev_depth, r.gbuff_prev_normals, r.gbuff_depth_reflection)
+        ti.set_out_of_bounds_reads("zero", r.gbuff_normals, r.gbuff_depth, r.gbuff_mat_id, r.spatial_reservoirs)
+
+    def _dm(self, op):
+        def f(a, b=0.0):
+            x, y, out = np.array([a], np.float32), np.array([b], np.float32), np.zeros(1, np.float32)
+            self.L.orc_unit_detmath(op, 1, self._fptr(x), self._fptr(y), self._fptr(out))
+            return out[0]
+        return f
+
+    def _random(self, index):
+        if self.stream == 3:
+            key, frame, pix = ("jitter", self.jitter_index), self.jitter_index, 0
+        else:
+            pix = int(index[1]) * self.W + int(index[0])
+            frame = self._frame
+            key = (self.stream, frame, pix)
+        st = self._cache.get(key)
+        if st is None:
+            out = np.zeros(2048, np.float32)
+            self.L.orc_unit_rng(C.c_uint32(self.cfg.seed), C.c_uint32(frame), C.c_uint32(pix), C.c_uint32(self.stream), 2048, self._fptr(out))
+            st = self._cache[key] = [out, 0]
+        st[1] += 1
+        return st[0][st[1] - 1]
+
+    # -- the session interface ------------------------------------------------------------------------------------------
+    def upload_voxels(self, mat, rgb):
+        self.r.world.voxel_material.a[...] = mat       # what the example scripts' kernels write through set_voxel (pathtracer.py:1325-1328)
+        self.r.world.voxel_color.a[...] = rgb
+
+    def upload_materials(self, table):
+        ml = self.r.mats.mat_list
+        names = ["subsurface", "metallic", "specular", "specular_tint", "roughness", "anisotropic", "sheen", "sheen_tint", "clearcoat",
+                 "clearcoat_gloss", "ior_minus_one"]
+        own = np.array([[*ml[i].base_col.to_list(), *[float(getattr(ml[i], n)) for n in names]] for i in range(128)], np.float32)
+        assert np.array_equal(own, np.asarray(table, np.float32)), "the product's material table differs from the reference's MaterialList"
+
+    def set_scene(self, s):
+        r = self.r
+        assert not s.use_physical_sky
+        r.light_direction[None] = list(s.light_direction)       # set_directional_light (pathtracer.py:139-144) with the values the
+        r.light_cone_cos_theta_max[None] = s.light_cos_theta_max  # boundary hands over (host.make_scene_params)
+        r.light_color[None] = list(s.light_color)
+        r.light_weight = float(s.light_weight)
+        r.floor_height[None] = s.floor_height
+        r.floor_color[None] = list(s.floor_color)
+        r.floor_material[None] = s.floor_material
+        r.background_color[None] = list(s.background_color)
+        r.use_physical_atmosphere[None] = 0
+
+    def set_camera(self, cam):
+        from voxel_rt2_amd import camera
+        r = self.r
+        view = np.array(cam.view, np.float32).reshape(4, 4)
+        proj = np.array(cam.proj, np.float32).reshape(4, 4)
+        r.set_camera_pos(*[float(x) for x in cam.pos])
+        r.set_max_samples(float(cam.max_accum_frames))
+        r.set_render_scale(float(cam.render_scale))
+        r.set_camera_is_moving(int(cam.camera_is_moving))
+        self.stream, self.jitter_index = 3, int(cam.jitter_index)
+        self._cache.pop(("jitter", self.jitter_index), None)
+        r.set_proj_mat(camera.to_glm_memory(proj))
+        r.set_view_mat(camera.to_glm_memory(view))
+        assert np.array_equal(self._m4(r.proj_mat_inv[None]), np.array(cam.proj_inv, np.float32).reshape(4, 4))
+        assert np.array_equal(self._m4(r.view_mat_inv[None]), np.array(cam.view_inv, np.float32).reshape(4, 4))
+
+    @staticmethod
+    def _m4(m):
+        return np.array([[float(m[i, j]) for j in range(4)] for i in range(4)], np.float32)
+
+    def prepare(self):
+        """prepare_data (pathtracer.py:314-323).  Its three 128^3 loops take minutes here: what they produce for one voxel grid is
+        kept for the later cases of this run (and, for development, across runs in $REFEXEC_PREP_CACHE)."""
+        import hashlib
+        import pickle
+        w = self.r.world
+        key = hashlib.sha256(w.voxel_material.a.tobytes() + w.voxel_color.a.tobytes()).hexdigest()[:16]
+        disk = os.environ.get("REFEXEC_PREP_CACHE")
+        path = os.path.join(disk, key + ".pkl") if disk else None
+        if key not in _PREPARED and path and os.path.exists(path):
+            _PREPARED[key] = pickle.load(open(path, "rb"))
+        if key not in _PREPARED:
+            self.r.prepare_data()
+            _PREPARED[key] = (w.voxel_color_texture.a.copy(), self.r.voxel_raytracer.occupancy.a.copy())
+            if path:
+                pickle.dump(_PREPARED[key], open(path, "wb"))
+        w.voxel_color_texture.a, self.r.voxel_raytracer.occupancy.a = (x.copy() for x in _PREPARED[key])
+
+    def accumulate(self, n=1):
+        """Renderer.accumulate (pathtracer.py:1310-1319), spelt out so that ti.random()'s stream follows the kernel."""
+        r, pt = self.r, self.pt
+        for _ in range(n):
+            self._cache.clear()
+            self.stream, self._frame = 0, r.current_frame
+            r.render(r.world.voxel_color_texture)
+            if pt.USE_RESTIR_PT:
+                self.stream = 1
+                r.current_frame = 0    # `self.current_frame` is a Python int: baked into the kernel at first compile (pathtracer.py:834)
+                try:
+                    r.spatial_GRIS(0, 24.0, 32, 1, r.world.voxel_color_texture)
+                finally:
+                    r.current_frame = self._frame
+            r.temporal_filter_prepass()
+            r.temporal_filter()
+            r.temporal_filter_specular()
+            r.current_spp += 1
+            r.current_frame += 1
+
+    def reset(self):
+        self.r.reset_framebuffer()
+
+    def end_frame(self):
+        self.r.copy_prev_matrices()
+
+    def fetch_hdr(self):
+        return np.ascontiguousarray(self.r.color_buffer.to_numpy().transpose(1, 0, 2))
+
+    def fetch_ldr(self):
+        img = self.r.fetch_image()
+        return np.ascontiguousarray(img.to_numpy().transpose(1, 0, 2))
+
+    def fetch_buffer(self, which):
+        from voxel_rt2_amd import _abi
+        r = self.r
+        t2 = lambda a: np.ascontiguousarray(a.transpose(1, 0) if a.ndim == 2 else a.transpose(1, 0, 2))  # noqa: E731
+        if which == _abi.BUF_GBUF_DEPTH:
+            return t2(r.gbuff_depth.to_numpy())[..., None]
+        if which == _abi.BUF_GBUF_NORMAL:
+            return t2(r.gbuff_normals.to_numpy()).view(np.uint16)
+        if which == _abi.BUF_GBUF_POSITION:
+            return t2(r.gbuff_position.to_numpy())
+        if which == _abi.BUF_GBUF_MAT:
+            return t2(r.gbuff_mat_id.to_numpy())[..., None]
+        if which == _abi.BUF_GBUF_REFL_DEPTH:
+            return t2(r.gbuff_depth_reflection.to_numpy())[..., None]
+        if which == _abi.BUF_HISTORY_DIFFUSE:
+            return np.ascontiguousarray(r.history_buffer.to_numpy()[:, :, 0, :].transpose(1, 0, 2))
+        if which == _abi.BUF_HISTORY_SPECULAR:
+            return np.ascontiguousarray(r.history_buffer_specular.to_numpy()[:, :, 0, :].transpose(1, 0, 2))
+        raise ValueError(which)
+
+    def close(self):
+        pass
+
+
+def config_of(case):
+    import make_golden
+    return make_golden.config_of(case)
+
+
+def main(argv):
+    import make_golden
+    libm = "--libm" in argv
+    names = [a for a in argv if not a.startswith("--")] or list(CASES)
+    os.makedirs(OUT, exist_ok=True)
+    for name in names:
+        case = CASES[name]
+        t = time.time()
+        sess = ReferenceSession(make_golden.config_of(case), libm=libm)
+        out = make_golden.run_case(sess, case)
+        path = os.path.join(OUT, name + ".npz")
+        if libm:
+            want = np.load(path)
+            for key in ("hdr", "ldr"):
+                a, b = out[key].astype(np.float64), want[key].astype(np.float64)
+                d = np.abs(a - b)
+                print(f"{name} [{key}] numpy's elementary functions instead of the contract's: {int((d > 0).sum())} of {d.size} values differ, "
+                      f"max |diff| {d.max():.3g}, max relative {np.nanmax(d / np.maximum(np.abs(b), 1e-6)):.3g}")
+            continue
+        np.savez_compressed(path, **out)
+        print(name, {k: (v.shape, str(v.dtype)) for k, v in out.items()}, os.path.getsize(path), "bytes", f"{time.time() - t:.0f} s", flush=True)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

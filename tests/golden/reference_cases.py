@@ -1,0 +1,11 @@
+"""The cases of tests/golden/reference/*.npz (pure data: imported by the generator make_reference_vectors.py and by
+tests/test_reference_vectors.py).  name -> (scene, scene seed, W, H, max depth, rng seed, ReSTIR, script): make_golden.CASES' format.
+W % 16 == 0 and H % 8 == 0: the reference's blocked field layout (pathtracer.py:74)."""
+CASES = {
+    "ref_s1_32x16_d4": ("s1", 0, 32, 16, 4, 0, False, [("accumulate", 2)]),
+    "ref_sunlit_48x24_d5": ("sunlit", 0, 48, 24, 5, 11, False, [("accumulate", 2), ("end_frame",), ("still", 2), ("accumulate", 1)]),
+    "ref_sunlit_restir_32x24_d4": ("sunlit", 0, 32, 24, 4, 7, True, [("accumulate", 2)]),
+    "ref_sunlit_moving_32x16_d4": ("sunlit", 0, 32, 16, 4, 9, False, [("accumulate", 2), ("end_frame",), ("move", 0.45), ("accumulate", 1),
+                                                                        ("end_frame",), ("still", 3), ("accumulate", 1)]),
+    "ref_dense_32x16_d3": ("dense", 12345, 32, 16, 3, 3, False, [("accumulate", 1)]),
+}

@@ -425,6 +425,7 @@ def select(c, a, f):
 # installs a function that receives the index of the struct-for iteration the draw happens in (None outside one).
 _random_source = [None]
 _loop_index = [None]
+_touched = []       # fields written during the running struct-for (their _pre / _writer are dropped when it ends)
 
 
 def set_random_source(fn_or_values):
@@ -443,8 +444,12 @@ def random(dtype=float):
 _oob_reads = ["error"]
 
 
-def set_out_of_bounds_reads(policy):
-    _oob_reads[0] = policy
+def set_out_of_bounds_reads(policy, *fields):
+    """"clamp": the nearest element; "zero": memory nobody wrote; "error" (default).  For the given fields, or for all."""
+    if not fields:
+        _oob_reads[0] = policy
+    for f in fields:
+        f._oob = policy
 
 
 class _Axes:
@@ -508,15 +513,48 @@ class _FieldBase:
         """Reads outside a multi-dimensional field are undefined in release-mode Taichi; the caller picks what they see:
         the nearest element ("clamp") or an error (default)."""
         k = self._key(idx)
-        if _oob_reads[0] == "clamp" and len(k) > 1:
-            k = tuple(_b.min(_b.max(a, 0), n - 1) for a, n in zip(k, self.shape))
+        if len(k) > 1 and not _b.all(0 <= a < n for a, n in zip(k, self.shape)):
+            policy = getattr(self, "_oob", None) or _oob_reads[0]
+            if policy == "clamp":
+                return tuple(_b.min(_b.max(a, 0), n - 1) for a, n in zip(k, self.shape))
+            if policy == "zero":
+                return None
+            raise IndexError(f"read at {k} outside a field of shape {self.shape}")
         return k
 
     def _indices(self):
-        for idx in _it.product(*[range(o, o + n) for n, o in zip(self.shape, self.offset)]):
-            _loop_index[0] = idx
-            yield idx
-        _loop_index[0] = None
+        """A struct-for is a PARALLEL loop: iterations run here one after another, but each sees the value an element had before
+        the loop wherever ANOTHER iteration has written it meanwhile (its own writes it reads back) -- the outcome of threads that
+        all read before any of them writes, which is also what the build decided for the reference's racy kernels (DESIGN.md
+        section 5).  Fields keep the overwritten values in _pre until the loop ends."""
+        outer = _loop_index[0]
+        try:
+            for idx in _it.product(*[range(o, o + n) for n, o in zip(self.shape, self.offset)]):
+                _loop_index[0] = idx if outer is None else outer
+                yield idx
+        finally:
+            _loop_index[0] = outer
+            if outer is None:
+                for f in _touched:
+                    f._pre, f._writer = {}, {}
+                del _touched[:]
+
+    _pre, _writer = {}, {}
+
+    def _note_write(self, k, old):
+        me = _loop_index[0]
+        if me is None:
+            return
+        if not self._pre:
+            self._pre, self._writer = {}, {}
+            _touched.append(self)
+        if k not in self._pre:
+            self._pre[k] = old
+        self._writer[k] = me
+
+    def _foreign(self, k):
+        """True when element k was written in this parallel loop by another iteration: the reader gets _pre[k]."""
+        return bool(self._pre) and k in self._pre and self._writer[k] != _loop_index[0]
 
     def __iter__(self):
         if len(self.shape) == 1:
@@ -536,8 +574,12 @@ class _Field(_FieldBase):
 
     def __getitem__(self, idx):
         k = self._read_key(idx)
+        if k is None:
+            return self.dtype(0)
         if len(k) == 1 and self.a.ndim == 1 and not 0 <= k[0] < self.a.shape[0]:
             return self.dtype(0)          # past the end: release-mode Taichi does not check; unwritten memory reads as zero here
+        if self._foreign(k):
+            return self._pre[k]
         return self.a[k]
 
     def __setitem__(self, idx, val):
@@ -546,6 +588,8 @@ class _Field(_FieldBase):
             grown = _np.zeros(k[0] + 1 + k[0] // 4, dtype=self.dtype)
             grown[: self.a.shape[0]] = self.a
             self.a = grown
+        if len(k) > 1:      # (1-D fields are only ever written through atomics here: every iteration must see those)
+            self._note_write(k, self.a[k])
         self.a[k] = _cast1(val, self.dtype)
 
     def fill(self, v): self.a[...] = v
@@ -561,7 +605,9 @@ class _BoundVector(Vector):
     """An element of a vector field: writes to components go through to the field (self.f[u, v].x += ...)."""
     __slots__ = ("_f", "_k")
 
-    def _sync(self): self._f.a[self._k] = self._v
+    def _sync(self):
+        self._f._note_write(self._k, self._f.a[self._k].copy())
+        self._f.a[self._k] = self._v
     def __setitem__(self, i, val):
         Vector.__setitem__(self, i, val); self._sync()
     def __setattr__(self, name, value):
@@ -580,15 +626,19 @@ class _VectorField(_FieldBase):
 
     def __getitem__(self, idx):
         k = self._read_key(idx)
+        if k is None:
+            return Vector._new([self.dtype(0)] * self.n)
         v = object.__new__(_BoundVector)
-        object.__setattr__(v, "_v", [self.dtype(x) for x in self.a[k]])
+        object.__setattr__(v, "_v", [self.dtype(x) for x in (self._pre[k] if self._foreign(k) else self.a[k])])
         object.__setattr__(v, "_f", self)
         object.__setattr__(v, "_k", k)
         return v
 
     def __setitem__(self, idx, val):
         vals = val._v if isinstance(val, Vector) else list(val)
-        self.a[self._key(idx)] = [_cast1(x, self.dtype) for x in vals]
+        k = self._key(idx)
+        self._note_write(k, self.a[k].copy())
+        self.a[k] = [_cast1(x, self.dtype) for x in vals]
 
     def fill(self, v): self.a[...] = _np.asarray(v._v if isinstance(v, Vector) else v, dtype=self.dtype)
     def from_numpy(self, arr): self.a[...] = arr
@@ -605,13 +655,20 @@ class _ObjectField(_FieldBase):
 
     def __getitem__(self, idx):
         k = self._read_key(idx)
+        if k is None:
+            return self._make()
+        if self._foreign(k):
+            return self._pre[k]
         o = self.objs.get(k)
         if o is None:
             o = self.objs[k] = self._make()
         return o
 
     def __setitem__(self, idx, val):
-        self.objs[self._key(idx)] = val._copy()
+        k = self._key(idx)
+        if self.shape:      # (shape-() fields are parameters, not per-pixel data)
+            self._note_write(k, self.objs.get(k) or self._make())
+        self.objs[k] = val._copy()
 
     def fill(self, v):
         self.objs = {}

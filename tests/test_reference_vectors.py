@@ -1,0 +1,69 @@
+"""tests/golden/reference/*.npz hold what THE REFERENCE'S OWN SOURCE FILES compute for a few small cases: they were written by
+tests/golden/make_reference_vectors.py, which imports /root/reference/renderer/*.py from where they lie and executes them under
+the Taichi-DSL emulation of tests/refexec (the Taichi JIT itself is not installed; that script's header lists what the emulation
+stands for and what the reference leaves undefined).  Here the oracle, the product's device code compiled for the host and -- on
+a GPU box -- libvrt_hip.so through the C ABI are driven through the same cases and must reproduce every buffer bit for bit:
+HDR, LDR, g-buffer (depth, packed normal, position, packed material, reflection depth) and both temporal histories."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import emu
+import orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(HERE, "golden", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+mg = _load("make_golden")
+CASES = _load("reference_cases").CASES
+
+
+def check(session, name):
+    got = mg.run_case(session, CASES[name])
+    want = np.load(os.path.join(HERE, "golden", "reference", name + ".npz"))
+    assert sorted(want.files) == sorted(got.keys())
+    for key in want.files:
+        a, b = np.ascontiguousarray(got[key]), want[key]
+        assert a.shape == b.shape and a.dtype == b.dtype, key
+        same = (a.view(np.uint8) == b.view(np.uint8)).reshape(a.shape[0], a.shape[1], -1).all(-1)
+        assert same.all(), f"{name}: {key} differs from the reference's output at {int((~same).sum())} of {same.size} pixels, first {np.argwhere(~same)[:4].tolist()}"
+
+
+def test_every_case_has_a_fixture():
+    have = {f[:-4] for f in os.listdir(os.path.join(HERE, "golden", "reference")) if f.endswith(".npz")}
+    assert have == set(CASES)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_equals_reference_source(name):
+    o = orc.Oracle(mg.config_of(CASES[name]), threads=4)
+    check(o, name)
+    o.close()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_emulated_device_code_equals_reference_source(name):
+    e = emu.Emulated(mg.config_of(CASES[name]))
+    check(e, name)
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("schedule", ["pool", "fused"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gpu_equals_reference_source(name, schedule, monkeypatch):
+    from voxel_rt2_amd import _lib
+    from voxel_rt2_amd._session import NativeSession
+    monkeypatch.setenv("VRT_RENDER", schedule)
+    g = NativeSession(_lib.load(), "vrt_", mg.config_of(CASES[name]))
+    check(g, name)
+    g.close()
