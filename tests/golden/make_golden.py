@@ -42,12 +42,23 @@ CASES = {
 }
 
 
+SKY_BUFS = {"sky_scattering": _abi.BUF_SKY_SCATTERING, "sky_transmittance": _abi.BUF_SKY_TRANSMITTANCE, "trans_lut": _abi.BUF_TRANS_LUT}
+
+
 def run_case(session, case):
-    """Drives any session object (oracle, emulation, GPU) through a case's script."""
-    scene, scene_seed, W, H, depth, seed, restir, script = case
+    """Drives any session object (oracle, emulation, GPU) through a case's script.  A ninth element (sky table size, cloud passes,
+    slices) turns the physical sky and its clouds on: the tables are computed before the first step, as Scene.finish() does."""
+    scene, scene_seed, W, H, depth, seed, restir, script = case[:8]
+    sky = case[8] if len(case) > 8 else None
     mat, rgb, params = scenes.SCENES[scene](scene_seed)
-    params = dict(params, use_physical_sky=0, use_clouds=0)
-    orc.setup(session, mat, rgb, params)
+    params = dict(params, use_physical_sky=int(bool(sky)), use_clouds=int(bool(sky)))
+    cloud = np.load(os.path.join(ROOT, "voxel_rt2_amd", "data", "cloud_texture.npy")) if sky else None
+    orc.setup(session, mat, rgb, params, cloud=cloud)
+    if sky:
+        for _ in range(sky[1]):
+            session.sky_accumulate_clouds(sky[1])
+        for s in range(sky[2]):
+            session.sky_compute_slice(s, sky[2])
     k = 1
     for step in script:
         if step[0] == "accumulate":
@@ -64,13 +75,17 @@ def run_case(session, case):
     out = {"hdr": session.fetch_hdr(), "ldr": session.fetch_ldr()}
     for name, which in BUFS.items():
         out[name] = session.fetch_buffer(which)
+    if sky:
+        for name, which in SKY_BUFS.items():
+            out[name] = session.fetch_buffer(which)
     return out
 
 
 def config_of(case):
-    scene, scene_seed, W, H, depth, seed, restir, script = case
+    scene, scene_seed, W, H, depth, seed, restir, script = case[:8]
     _, _, params = scenes.SCENES[scene](scene_seed)
-    return host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=depth, seed=seed, use_restir=restir)
+    return host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=depth, seed=seed, use_restir=restir,
+                            sky_res=case[8][0] if len(case) > 8 else 0)
 
 
 if __name__ == "__main__":

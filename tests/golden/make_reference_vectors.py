@@ -55,7 +55,7 @@ class ReferenceSession:
         import renderer.pathtracer as pt
         self.ti, self.pt, self.cfg = ti, pt, cfg
         self.W, self.H = cfg.width, cfg.height
-        assert cfg.grid_res == 128 and cfg.sky_res == 0
+        assert cfg.grid_res == 128
         pt.MAX_RAY_DEPTH = cfg.max_depth            # module constants of the reference (pathtracer.py:15-17), set from outside
         pt.USE_RESTIR_PT = bool(cfg.use_restir)
         self.L = orc.lib()
@@ -71,6 +71,15 @@ class ReferenceSession:
         ti.set_out_of_bounds_reads("clamp", r.color_buffer, r.color_buffer_specular, r.history_buffer, r.history_buffer_specular,
                                    r.history_buffer_specular_depth, r.gbuff_prev_depth, r.gbuff_prev_normals, r.gbuff_depth_reflection)
         ti.set_out_of_bounds_reads("zero", r.gbuff_normals, r.gbuff_depth, r.gbuff_mat_id, r.spatial_reservoirs)
+        if cfg.sky_res:
+            # the skybox tables' size is a constant of Atmos.__init__ (atmos.py:66-69: 3840, far beyond a Python loop); the kernels
+            # read it from these instance attributes, which are replaced here by the same expressions at the case's size
+            R, a = int(cfg.sky_res), r.atmos
+            a.skybox_fres = ti.Vector([1.0 / R, 1.0 / R])
+            a.skybox_res = ti.Vector([R, R])
+            a.skybox_scattering = ti.Vector.field(3, dtype=ti.f32, shape=(R, R))
+            a.skybox_transmittance = ti.Vector.field(3, dtype=ti.f32, shape=(R, R))
+        self._cloud_pass = 0
 
     def _dm(self, op):
         def f(a, b=0.0):
@@ -82,15 +91,20 @@ class ReferenceSession:
     def _random(self, index):
         if self.stream == 3:
             key, frame, pix = ("jitter", self.jitter_index), self.jitter_index, 0
+        elif self.stream == 2:    # sky precompute (oracle/orc_atmos.h: frame = the kernel's tag or the cloud pass, texel u * R + v)
+            pix = int(index[0]) * int(self.cfg.sky_res) + int(index[1]) if index is not None else 0
+            frame = self._frame
+            key = (2, frame, pix)
         else:
             pix = int(index[1]) * self.W + int(index[0])
             frame = self._frame
             key = (self.stream, frame, pix)
         st = self._cache.get(key)
-        if st is None:
-            out = np.zeros(2048, np.float32)
-            self.L.orc_unit_rng(C.c_uint32(self.cfg.seed), C.c_uint32(frame), C.c_uint32(pix), C.c_uint32(self.stream), 2048, self._fptr(out))
-            st = self._cache[key] = [out, 0]
+        if st is None or st[1] >= len(st[0]):
+            n = 1024 if st is None else 8 * len(st[0])      # (the probe restarts the stream: ask for a longer prefix)
+            out = np.zeros(n, np.float32)
+            self.L.orc_unit_rng(C.c_uint32(self.cfg.seed), C.c_uint32(frame), C.c_uint32(pix), C.c_uint32(self.stream), n, self._fptr(out))
+            st = self._cache[key] = [out, 0 if st is None else st[1]]
         st[1] += 1
         return st[0][st[1] - 1]
 
@@ -106,9 +120,16 @@ class ReferenceSession:
         own = np.array([[*ml[i].base_col.to_list(), *[float(getattr(ml[i], n)) for n in names]] for i in range(128)], np.float32)
         assert np.array_equal(own, np.asarray(table, np.float32)), "the product's material table differs from the reference's MaterialList"
 
+    def upload_cloud_texture(self, tex):
+        """atmos.py:85-90 reads textures/cloud_texture.jpg through ti.tools.imread; the product ships the decoded array
+        (voxel_rt2_amd/data/cloud_texture.npy).  They must be the same bytes."""
+        a = self.r.atmos
+        a.load_textures()
+        assert np.array_equal(a.cloud_tex.to_numpy(), np.asarray(tex)), "data/cloud_texture.npy differs from the reference's texture as imread decodes it"
+
     def set_scene(self, s):
         r = self.r
-        assert not s.use_physical_sky
+        assert bool(s.use_physical_sky) == bool(self.cfg.sky_res)
         r.light_direction[None] = list(s.light_direction)       # set_directional_light (pathtracer.py:139-144) with the values the
         r.light_cone_cos_theta_max[None] = s.light_cos_theta_max  # boundary hands over (host.make_scene_params)
         r.light_color[None] = list(s.light_color)
@@ -117,7 +138,8 @@ class ReferenceSession:
         r.floor_color[None] = list(s.floor_color)
         r.floor_material[None] = s.floor_material
         r.background_color[None] = list(s.background_color)
-        r.use_physical_atmosphere[None] = 0
+        r.use_physical_atmosphere[None] = int(s.use_physical_sky)
+        r.atmos.use_clouds[None] = int(s.use_clouds)
 
     def set_camera(self, cam):
         from voxel_rt2_amd import camera
@@ -151,11 +173,44 @@ class ReferenceSession:
         if key not in _PREPARED and path and os.path.exists(path):
             _PREPARED[key] = pickle.load(open(path, "rb"))
         if key not in _PREPARED:
+            sky, self.r.use_physical_atmosphere[None] = self.r.use_physical_atmosphere[None], 0   # (the sky part runs below, with its stream)
             self.r.prepare_data()
+            self.r.use_physical_atmosphere[None] = sky
             _PREPARED[key] = (w.voxel_color_texture.a.copy(), self.r.voxel_raytracer.occupancy.a.copy())
             if path:
                 pickle.dump(_PREPARED[key], open(path, "wb"))
         w.voxel_color_texture.a, self.r.voxel_raytracer.occupancy.a = (x.copy() for x in _PREPARED[key])
+        r = self.r
+        if r.use_physical_atmosphere[None] == 1:     # the rest of prepare_data (pathtracer.py:317-323; the textures are loaded above)
+            self.stream, self._frame = 2, 0x1000     # TAG_AMBIENT
+            self._cache.clear()
+            t = time.time()
+            lut = os.path.join(disk, "trans_lut.npy") if disk else None
+            if "lut" not in _PREPARED and lut and os.path.exists(lut):
+                _PREPARED["lut"] = np.load(lut)
+            if "lut" not in _PREPARED:
+                r.atmos.generate_transmittance_lut()
+                _PREPARED["lut"] = r.atmos.trans_LUT.a.copy()
+                if lut:
+                    np.save(lut, _PREPARED["lut"])
+            r.atmos.trans_LUT.a = _PREPARED["lut"].copy()
+            print(f"  transmittance LUT {time.time() - t:.0f} s", flush=True)
+            r.atmos.compute_cloud_ambient(r.light_direction[None], r.light_color[None] * r.light_weight, r.light_cone_cos_theta_max[None])
+            r.atmos.skybox_scattering.fill(self.ti.Vector([0., 0., 0.]))
+            r.atmos.skybox_transmittance.fill(self.ti.Vector([0., 0., 0.]))
+
+    def sky_accumulate_clouds(self, max_samples):
+        self.stream, self._frame = 2, self._cloud_pass
+        self._cache.clear()
+        self.r.accumulate_clouds(max_samples)
+        self._cloud_pass += 1
+
+    def sky_compute_slice(self, slice_idx, max_slices):
+        self.stream, self._frame = 2, 0x2000         # TAG_SKYBOX
+        self._cache.clear()
+        t = time.time()
+        self.r.compute_atmosphere(slice_idx, max_slices)
+        print(f"  sky slice {slice_idx + 1} / {max_slices} {time.time() - t:.0f} s", flush=True)
 
     def accumulate(self, n=1):
         """Renderer.accumulate (pathtracer.py:1310-1319), spelt out so that ti.random()'s stream follows the kernel."""
@@ -208,10 +263,57 @@ class ReferenceSession:
             return np.ascontiguousarray(r.history_buffer.to_numpy()[:, :, 0, :].transpose(1, 0, 2))
         if which == _abi.BUF_HISTORY_SPECULAR:
             return np.ascontiguousarray(r.history_buffer_specular.to_numpy()[:, :, 0, :].transpose(1, 0, 2))
+        if which == _abi.BUF_SKY_SCATTERING:
+            return r.atmos.skybox_scattering.to_numpy()
+        if which == _abi.BUF_SKY_TRANSMITTANCE:
+            return r.atmos.skybox_transmittance.to_numpy()
+        if which == _abi.BUF_TRANS_LUT:
+            return r.atmos.trans_LUT.to_numpy().view(np.uint16)
         raise ValueError(which)
 
     def close(self):
         pass
+
+
+def ray_vectors(path, n=600, seed=4):
+    """VoxelOctreeRaytracer.raytrace (raytracer.py:72-155, the hot loop) on its own: rays from inside and outside the grid of the
+    sun-lit scene, toward it and past it, axis-parallel ones (a zero direction component: the 0 * inf of :94, 133), grazing ones
+    along cell faces, and origins exactly on cell boundaries."""
+    import taichi as ti
+    import make_golden
+    from voxel_rt2_amd import scenes
+    case = ("sunlit", 0, 16, 8, 2, 0, False, [])
+    sess = ReferenceSession(make_golden.config_of(case))
+    mat, rgb, _ = scenes.scene_sunlit(0)
+    sess.upload_voxels(mat, rgb)
+    sess.prepare()
+    rt = sess.r.voxel_raytracer
+    rng = np.random.default_rng(seed)
+    org = rng.uniform(-24.0, 152.0, (n, 3)).astype(np.float32)
+    org[: n // 3] = rng.uniform(0.0, 128.0, (n // 3, 3)).astype(np.float32)           # inside the grid
+    solid = np.argwhere(mat > 0)
+    tgt = (solid[rng.integers(0, len(solid), n)] + rng.uniform(-3.0, 4.0, (n, 3))).astype(np.float32)   # toward (or just past) solid voxels
+    d = tgt - org
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    for k in range(0, n, 7):
+        d[k, rng.integers(0, 3)] = 0.0                                              # axis-parallel component
+    for k in range(3, n, 11):
+        org[k] = np.floor(org[k])                                                    # exactly on cell boundaries
+    for k in range(5, n, 13):
+        a = rng.integers(0, 3)
+        d[k] = 0.0
+        d[k, a] = rng.choice([-1.0, 1.0])                                            # along an axis
+    out = dict(origin=org, direction=d, distance=np.zeros(n, np.float32), cell=np.zeros((n, 3), np.int32),
+               normal=np.zeros((n, 3), np.float32), iters=np.zeros(n, np.int32))
+    eps = 1e-6   # math_utils.py:5, as _trace_voxel passes it (pathtracer.py:201-202)
+    for k in range(n):
+        dist, cell, nor, iters = rt.raytrace(ti.Vector([x for x in org[k]]), ti.Vector([x for x in d[k]]), eps, np.inf)
+        out["distance"][k], out["iters"][k] = dist, iters
+        out["cell"][k], out["normal"][k] = cell.to_list(), nor.to_list()
+    np.savez_compressed(path, **out)
+    hit = np.isfinite(out["distance"])
+    print(os.path.basename(path), f"{n} rays: {int(hit.sum())} hits, {int(np.isinf(out['distance']).sum())} misses, {int(np.isnan(out['distance']).sum())} NaN, "
+          f"iterations {out['iters'].min()}..{out['iters'].max()}", flush=True)
 
 
 def config_of(case):
@@ -222,10 +324,17 @@ def config_of(case):
 def main(argv):
     import make_golden
     libm = "--libm" in argv
-    names = [a for a in argv if not a.startswith("--")] or list(CASES)
+    names = [a for a in argv if not a.startswith("--")] or list(CASES) + ["rays"]
     os.makedirs(OUT, exist_ok=True)
+    if "rays" in names:
+        names.remove("rays")
+        if not os.path.exists(os.path.join(OUT, "rays_sunlit.npz")) or "--force" in argv:
+            ray_vectors(os.path.join(OUT, "rays_sunlit.npz"))
     for name in names:
         case = CASES[name]
+        if os.path.exists(os.path.join(OUT, name + ".npz")) and not libm and "--force" not in argv:
+            print(name, "exists (--force rewrites it)")
+            continue
         t = time.time()
         sess = ReferenceSession(make_golden.config_of(case), libm=libm)
         out = make_golden.run_case(sess, case)

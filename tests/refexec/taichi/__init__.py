@@ -492,6 +492,26 @@ def _idx_tuple(idx):
     return (_b.int(idx),)
 
 
+def _parallel(indices):
+    """The outermost for of a kernel over a field or an ndrange is a PARALLEL loop: iterations run here one after another, but
+    each sees the value an element had before the loop wherever ANOTHER iteration has written it meanwhile (its own writes it reads
+    back) -- the outcome of threads that all read before any of them writes, which is also what the build decided for the
+    reference's racy kernels.  Fields keep the overwritten values in _pre until the loop ends.  The index
+    of the running iteration is what ti.random()'s source receives.  Loops nested inside are plain serial loops."""
+    outer = _loop_index[0]
+    try:
+        for idx in indices:
+            if outer is None:
+                _loop_index[0] = idx
+            yield idx
+    finally:
+        _loop_index[0] = outer
+        if outer is None:
+            for f in _touched:
+                f._pre, f._writer = {}, {}
+            del _touched[:]
+
+
 class _FieldBase:
     """Dense field; struct-for iteration (`for u, v in f`, `for I in ti.grouped(f)`) visits every index once, row-major (the
     order is unspecified in Taichi), and publishes the index to ti.random()'s source."""
@@ -523,21 +543,7 @@ class _FieldBase:
         return k
 
     def _indices(self):
-        """A struct-for is a PARALLEL loop: iterations run here one after another, but each sees the value an element had before
-        the loop wherever ANOTHER iteration has written it meanwhile (its own writes it reads back) -- the outcome of threads that
-        all read before any of them writes, which is also what the build decided for the reference's racy kernels (DESIGN.md
-        section 5).  Fields keep the overwritten values in _pre until the loop ends."""
-        outer = _loop_index[0]
-        try:
-            for idx in _it.product(*[range(o, o + n) for n, o in zip(self.shape, self.offset)]):
-                _loop_index[0] = idx if outer is None else outer
-                yield idx
-        finally:
-            _loop_index[0] = outer
-            if outer is None:
-                for f in _touched:
-                    f._pre, f._writer = {}, {}
-                del _touched[:]
+        return _parallel(_it.product(*[range(o, o + n) for n, o in zip(self.shape, self.offset)]))
 
     _pre, _writer = {}, {}
 
@@ -816,9 +822,15 @@ def _store_names(nodes):
 
 
 class _Scoping(_ast.NodeTransformer):
-    def __init__(self, byref_params):
+    def __init__(self, byref_params, remap):
         self.byref_params = byref_params
+        self.remap = remap
         self.tmp = 0
+
+    def visit_Name(self, node):
+        if isinstance(node.ctx, _ast.Load) and node.id in self.remap:
+            return _ast.Name(id=self.remap[node.id], ctx=_ast.Load())
+        return node
 
     # x = value / a, b = value / x += value
     def visit_Assign(self, node):
@@ -923,6 +935,11 @@ def _param_info(fn):
     return fdef, names, [t for t in tmpl if t in stored]
 
 
+_KERNEL_BUILTINS = {"abs": abs, "max": max, "min": min, "pow": pow, "round": round, "int": lambda x=0: _cast1(x, _np.int32),
+                    "float": lambda x=0.0: _cast1(x, _np.float32), "all": lambda x: x.all() if isinstance(x, Vector) else _b.all(x),
+                    "any": lambda x: x.any() if isinstance(x, Vector) else _b.any(x)}
+
+
 def _compile(fn, fdef, byref):
     fdef.decorator_list = []
     _ast.increment_lineno(fdef, fn.__code__.co_firstlineno - 1)
@@ -931,7 +948,13 @@ def _compile(fn, fdef, byref):
     fdef.returns = None
     params = {a.arg for a in fdef.args.args}
     body_locals = [n for n in _store_names(fdef.body) if n not in params]
-    fdef = _Scoping(byref).visit(fdef)
+    # inside kernels abs / max / min / pow / round / int / float / all / any act on typed values and vectors the Taichi way: their
+    # uses are renamed (the module's own globals stay what they are for its plain Python code), unless the module or the function
+    # binds the name to something else (from taichi.math import * brings its own pow / max / min)
+    g = fn.__globals__
+    remap = {key: "__ti_b_" + key for key in _KERNEL_BUILTINS
+             if (key not in g or g[key] is getattr(_b, key, None)) and key not in params and key not in body_locals}
+    fdef = _Scoping(byref, remap).visit(fdef)
     if byref:
         vals = _ast.Tuple(elts=[_ast.Name(id=p, ctx=_ast.Load()) for p in byref], ctx=_ast.Load())
         fdef.body.append(_ast.Return(value=_ast.Tuple(elts=[_ast.Constant(None), vals], ctx=_ast.Load())))
@@ -943,15 +966,10 @@ def _compile(fn, fdef, byref):
     fdef.body = doc + pre + fdef.body
     tree = _ast.Module(body=[fdef], type_ignores=[])
     _ast.fix_missing_locations(tree)
-    g = fn.__globals__
     g["__ti_copy"], g["__ti_atomic"], g["__ti_assign"], g["__ti_assign_tuple"], g["__ti_unset"] = _copy, _atomic, _assign, _assign_tuple, _UNSET
     g["__ti_binop"] = _binop
-    # inside kernels the builtins act on typed values / vectors the Taichi way
-    for key, v in (("abs", abs), ("max", max), ("min", min), ("pow", pow), ("round", round), ("int", lambda x=0: _cast1(x, _np.int32)),
-                   ("float", lambda x=0.0: _cast1(x, _np.float32)), ("all", lambda x: x.all() if isinstance(x, Vector) else _b.all(x)),
-                   ("any", lambda x: x.any() if isinstance(x, Vector) else _b.any(x))):
-        if key not in g or g[key] is getattr(_b, key, None):
-            g[key] = v
+    for key, v in remap.items():
+        g[v] = _KERNEL_BUILTINS[key]
     ns = {}
     exec(compile(tree, _inspect.getsourcefile(fn) or "<ti.func>", "exec"), g, ns)
     return ns[fdef.name]
@@ -1020,7 +1038,7 @@ def grouped(it):
         for idx in it._indices():
             yield Vector(list(idx))
         return
-    for idx in it:
+    for idx in _parallel(it):
         yield Vector(list(idx) if isinstance(idx, tuple) else [idx])
 
 

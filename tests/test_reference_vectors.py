@@ -40,6 +40,7 @@ def check(session, name):
 
 def test_every_case_has_a_fixture():
     have = {f[:-4] for f in os.listdir(os.path.join(HERE, "golden", "reference")) if f.endswith(".npz")}
+    have.discard("rays_sunlit")    # single rays, test_oracle_rays_equal_reference_source
     assert have == set(CASES)
 
 
@@ -67,3 +68,29 @@ def test_gpu_equals_reference_source(name, schedule, monkeypatch):
     g = NativeSession(_lib.load(), "vrt_", mg.config_of(CASES[name]))
     check(g, name)
     g.close()
+
+
+def test_oracle_rays_equal_reference_source():
+    """600 rays through VoxelOctreeRaytracer.raytrace as the reference's raytracer.py computes them (rays_sunlit.npz): distance and
+    iteration count for every ray -- NaN distances included (axis-parallel rays that start outside their slab: 0 * inf, raytracer.py:94,
+    133) -- and, for hits, the voxel and the face normal.  On a miss the reference's cell / normal are whatever its last step left
+    OUTSIDE the grid, where its own occupancy reads are out of bounds (undefined; the build reads "empty" there):
+    not compared, nothing downstream reads them (pathtracer.py:205)."""
+    from voxel_rt2_amd import host, scenes
+    v = np.load(os.path.join(HERE, "golden", "reference", "rays_sunlit.npz"))
+    mat, rgb, params = scenes.scene_sunlit(0)
+    o = orc.Oracle(host.make_config(16, 8, max_depth=2), threads=1)
+    orc.setup(o, mat, rgb, params)
+    n = len(v["distance"])
+    hits = 0
+    for k in range(n):
+        got = o.raytrace(v["origin"][k], v["direction"][k], 1e-6, np.inf)
+        want = v["distance"][k]
+        assert np.float32(got["distance"]).view(np.uint32) == want.view(np.uint32) or (np.isnan(got["distance"]) and np.isnan(want)), k
+        assert got["iters"] == v["iters"][k], k
+        if np.isfinite(want):
+            hits += 1
+            assert list(got["cell"]) == list(v["cell"][k]), k
+            assert np.array_equal(got["normal"], v["normal"][k]), k
+    assert hits > 300 and np.isnan(v["distance"]).sum() > 10 and np.isinf(v["distance"]).sum() > 100
+    o.close()
