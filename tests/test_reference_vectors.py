@@ -28,13 +28,25 @@ CASES = _load("reference_cases").CASES
 
 
 def check(session, name):
+    """Every buffer, every pixel, bit for bit -- except the pixels a fixture lists in `undefined_px`: there one of the path's rays
+    left the grid a rounding error before the reference's own `far` test caught it, and the reference's bit index for the cell
+    outside the grid addressed another cell's SET bit (make_reference_vectors.py; only the dense grid has such pixels).  The
+    reference's value there is an artefact of undefined indexing, the build reads "empty" outside the grid."""
     got = mg.run_case(session, CASES[name])
     want = np.load(os.path.join(HERE, "golden", "reference", name + ".npz"))
-    assert sorted(want.files) == sorted(got.keys())
-    for key in want.files:
+    skip = want["undefined_px"] if "undefined_px" in want.files else np.zeros((got["hdr"].shape[0], got["hdr"].shape[1]), bool)
+    assert skip.sum() <= 0.01 * skip.size
+    spread = skip.copy()    # the reflection-depth prepass averages a 4x4 box (offsets -1..2, pathtracer.py:1030-1045)
+    for dy in range(-2, 2):
+        for dx in range(-2, 2):
+            spread |= np.roll(np.roll(skip, dy, 0), dx, 1)
+    assert sorted(f for f in want.files if f != "undefined_px") == sorted(got.keys())
+    for key in got:
         a, b = np.ascontiguousarray(got[key]), want[key]
         assert a.shape == b.shape and a.dtype == b.dtype, key
         same = (a.view(np.uint8) == b.view(np.uint8)).reshape(a.shape[0], a.shape[1], -1).all(-1)
+        if same.shape == skip.shape:
+            same |= spread if key == "gbuf_refl_depth" else skip
         assert same.all(), f"{name}: {key} differs from the reference's output at {int((~same).sum())} of {same.size} pixels, first {np.argwhere(~same)[:4].tolist()}"
 
 
