@@ -1,5 +1,5 @@
-/* orc_api.cpp -- ORACLE (test infrastructure, not product code).  PARITY UNPINNED (see
- * orc_renderer.h).  C entry points over the CPU restatement, loaded with ctypes by tests/,
+/* orc_api.cpp -- ORACLE (test infrastructure, not product code).  Parity status: see
+ * orc_renderer.h.  C entry points over the CPU restatement, loaded with ctypes by tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg ONLY.  The product library
  * (voxel_rt2_amd/csrc) never includes, links or calls anything in this directory.
  *

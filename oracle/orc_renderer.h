@@ -1,7 +1,11 @@
-/* orc_renderer.h -- ORACLE (test infrastructure, not product code).  PARITY UNPINNED: the
- * reference ships no tests / golden vectors and its Taichi runtime is not installable here
- * (SURVEY.md section 8c), so this restatement is pinned only by hand-derived known-answer and
- * property tests under tests/.
+/* orc_renderer.h -- ORACLE (test infrastructure, not product code).  PARITY: the reference ships
+ * no tests / golden vectors and its Taichi runtime is not installable here,
+ * so there is no reference build to compare with.  This restatement is pinned (a) against the
+ * reference's own source files executed under a host emulation of the Taichi DSL
+ * (tests/refexec, tests/golden/make_reference_vectors.py -> tests/golden/reference/*.npz,
+ * tests/test_reference_vectors.py: whole frames and single rays, bit for bit) and (b) by
+ * hand-derived known-answer and property tests under tests/.  Not pinned: what the Taichi
+ * compiler itself does to that source (fast-math, its own elementary functions).
  *
  * Literal CPU restatement of /root/reference/renderer/pathtracer.py class Renderer: ray
  * generation, next_hit, the render kernel, spatial_GRIS / shift, the three temporal kernels,

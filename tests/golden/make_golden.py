@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Regenerates tests/golden/*.npz with the CPU oracle (oracle/ -- the restatement of the reference path).
 
-These are NOT outputs of the reference: it only runs through the Taichi JIT, which cannot be installed here
-("parity unpinned").  They freeze what the oracle computes today for a few small,
+These are NOT outputs of the reference (those are tests/golden/reference/, written by make_reference_vectors.py from the
+reference's own source at sizes a Python loop can finish).  They freeze what the oracle computes today for a few small,
 fixed cases, so that (a) a change to the oracle that alters results is noticed on the CPU and (b) the GPU box
 can check libvrt_hip.so against committed data even without rebuilding the oracle (tests/test_golden.py).
 
