@@ -84,14 +84,16 @@ class ReferenceSession:
         # error short of `far` (raytracer.py:104) takes one more step with a cell coordinate of -1 or 128; linearize_index (:34-37)
         # then addresses ANOTHER cell's bit (x = 128 is x = 0 of the next row) or memory outside the level.  Undefined in the
         # reference (its levels >= 2 already live outside the allocation); the build reads "empty" there (DESIGN.md
-        # section 5).  Pixels whose paths got a SET bit from such a read are recorded: the reference's value there is an artefact
-        # of that indexing (a black speck on the grid's face), and the comparison leaves them out.
+        # section 5).  A set bit read that way at a COARSE level only makes the walk descend where it could have stepped (frequent, and
+        # without effect on what is hit); at level 0 it is reported as a hit on a voxel outside the grid.  Pixels whose paths got
+        # such a hit are recorded: the reference's value there is an artefact of that indexing (a black speck on the grid's
+        # face), and the comparison leaves them out.
         self.undefined_px = np.zeros((self.H, self.W), bool)
         rt, inner = r.voxel_raytracer, type(r.voxel_raytracer).query_occupancy
 
         def query_occupancy(ipos, lod):
             hit = inner(rt, ipos, lod)
-            if hit:
+            if hit and int(lod) == 0:
                 res = rt.voxel_grid_res >> int(lod)
                 if not all(0 <= int(c) < res for c in ipos):
                     idx = ti._loop_index[0]
@@ -359,7 +361,7 @@ def main(argv):
         out = make_golden.run_case(sess, case)
         if sess.undefined_px.any():
             out["undefined_px"] = sess.undefined_px
-            print(f"  {int(sess.undefined_px.sum())} pixels took a set bit from an occupancy read outside the grid: {np.argwhere(sess.undefined_px).tolist()}")
+            print(f"  {int(sess.undefined_px.sum())} pixels hit a 'voxel' outside the grid (a set level-0 bit read through an index that left the grid): {np.argwhere(sess.undefined_px).tolist()}")
         path = os.path.join(OUT, name + ".npz")
         if libm:
             want = np.load(path)
