@@ -106,3 +106,71 @@ def test_oracle_rays_equal_reference_source():
             assert np.array_equal(got["normal"], v["normal"][k]), k
     assert hits > 300 and np.isnan(v["distance"]).sum() > 10 and np.isinf(v["distance"]).sum() > 100
     o.close()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _same(got, want):
+    """Bit equality, any NaN equal to any NaN (payloads are not part of the contract)."""
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    return bool(np.all((_bits(got) == _bits(want)) | (np.isnan(got) & np.isnan(want))))
+
+
+def test_oracle_functions_equal_reference_source():
+    """functions.npz: single functions of the reference on random arguments (make_reference_vectors.function_vectors) -- the Disney
+    BSDF's evaluation, pdfs and sampler on 300 random materials, cone sampling, the packing helpers, hash3, the tone curve, a
+    reservoir's storage round trip and 150 reconnection shifts -- against the oracle's probes, bit for bit."""
+    import ctypes as C
+    from voxel_rt2_amd import host, scenes
+    v = np.load(os.path.join(HERE, "golden", "reference", "functions.npz"))
+    L, f = orc.lib(), orc.fptr
+    n = len(v["mat"])
+    for k in range(n):
+        a = [np.ascontiguousarray(v[key][k]) for key in ("mat", "v", "n", "l")]
+        out = np.zeros(7, np.float32)
+        L.orc_unit_bsdf_eval(*[f(x) for x in a], f(out))
+        assert _same(out, v["eval"][k]), ("eval", k, out, v["eval"][k])
+        o1 = np.zeros(1, np.float32)
+        L.orc_unit_lobe_pdf(*[f(x) for x in a], int(v["lobe"][k]), f(o1))
+        assert _same(o1[0], v["lobe_pdf"][k]), ("lobe pdf", k)
+        smp = np.zeros((4, 8), np.float32)
+        L.orc_unit_bsdf_sample(f(a[0]), f(a[1]), f(a[2]), C.c_uint32(int(v["sample_seed"]) + k), 4, f(smp))
+        assert _same(smp, v["sample"][k]), ("sample", k, smp, v["sample"][k])
+    assert len({int(x) for x in v["sample"][:, :, 7].ravel()}) == 3     # every lobe was sampled
+    for k in range(len(v["cone_cos"])):
+        out = np.zeros((3, 3), np.float32)
+        L.orc_unit_sample_cone(C.c_float(float(v["cone_cos"][k])), f(np.ascontiguousarray(v["cone_n"][k])), C.c_uint32(4), 3, f(out))
+        assert _same(out, v["cone"][k]), ("cone", k)
+    for k in range(len(v["oct_in"])):
+        code, dec = np.zeros(2, np.uint16), np.zeros(3, np.float32)
+        L.orc_unit_oct_encode(f(np.ascontiguousarray(v["oct_in"][k])), f(code))
+        want = v["oct_code"][k]
+        nan16 = lambda h: (h & 0x7C00) == 0x7C00 and (h & 0x3FF) != 0  # noqa: E731
+        assert all(int(c) == int(w) or (nan16(int(c)) and nan16(int(w))) for c, w in zip(code, want)), ("oct encode", k, code, want)
+        L.orc_unit_oct_decode(f(np.ascontiguousarray(want)), f(dec))
+        assert _same(dec, v["oct_out"][k]), ("oct decode", k)
+    for k in range(len(v["matenc"])):
+        assert L.orc_unit_encode_material(int(v["matenc_id"][k]), f(np.ascontiguousarray(v["matenc_albedo"][k]))) == int(v["matenc"][k])
+    for k in range(len(v["hash_out"])):
+        assert L.orc_unit_hash3(*[int(x) for x in v["hash_in"][k]]) == int(v["hash_out"][k])
+    out = np.zeros(len(v["uchimura_in"]), np.float32)
+    L.orc_unit_uchimura(f(np.ascontiguousarray(v["uchimura_in"])), len(out), f(out))
+    assert _same(out, v["uchimura_out"])
+    for k in range(len(v["res_in"])):
+        out = np.zeros(23, np.float32)
+        L.orc_unit_reservoir_roundtrip(f(np.ascontiguousarray(v["res_in"][k])), f(out))
+        assert _same(out, v["res_out"][k]), ("reservoir", k, out, v["res_out"][k])
+    mat, rgb, params = scenes.scene_sunlit(0)
+    o = orc.Oracle(host.make_config(16, 8, max_depth=2), threads=1)
+    orc.setup(o, mat, rgb, params)
+    zero_jac = 0
+    for k in range(len(v["shift_out"])):
+        a = [np.ascontiguousarray(v[key][k]) for key in ("shift_dst_pos", "shift_dst_n", "shift_dst_mat", "shift_src_pos", "shift_sample")]
+        out = np.zeros(7, np.float32)
+        L.orc_unit_shift(C.c_void_p(o._ctx), *[f(x) for x in a], f(out))
+        assert _same(out, v["shift_out"][k]), ("shift", k, out, v["shift_out"][k])
+        zero_jac += out[6] == 0.0
+    assert 10 < zero_jac < len(v["shift_out"]) - 10      # both rejected and accepted shifts
+    o.close()
