@@ -202,7 +202,7 @@ class ReferenceSession:
                 pickle.dump(_PREPARED[key], open(path, "wb"))
         w.voxel_color_texture.a, self.r.voxel_raytracer.occupancy.a = (x.copy() for x in _PREPARED[key])
         r = self.r
-        if r.use_physical_atmosphere[None] == 1:     # the rest of prepare_data (pathtracer.py:317-323; the textures are loaded above)
+        if r.use_physical_atmosphere[None] == 1 and not getattr(self, "tables_given", False):     # the rest of prepare_data (pathtracer.py:317-323; the textures are loaded above)
             self.stream, self._frame = 2, 0x1000     # TAG_AMBIENT
             self._cache.clear()
             t = time.time()
@@ -219,6 +219,10 @@ class ReferenceSession:
             r.atmos.compute_cloud_ambient(r.light_direction[None], r.light_color[None] * r.light_weight, r.light_cone_cos_theta_max[None])
             r.atmos.skybox_scattering.fill(self.ti.Vector([0., 0., 0.]))
             r.atmos.skybox_transmittance.fill(self.ti.Vector([0., 0., 0.]))
+
+    def upload_sky(self, scat, trans):
+        self.r.atmos.skybox_scattering.from_numpy(scat)
+        self.r.atmos.skybox_transmittance.from_numpy(trans)
 
     def sky_accumulate_clouds(self, max_samples):
         self.stream, self._frame = 2, self._cloud_pass
@@ -480,8 +484,37 @@ def config_of(case):
     return make_golden.config_of(case)
 
 
+def check_golden(names):
+    """tests/golden/*.npz are written by the ORACLE (make_golden.py).  This runs the reference's own source on those same cases,
+    where their frame fits its blocked layout, and reports whether it reproduces them -- the larger frames, fused launches and
+    longer scripts of that set, checked once in the build container (log: tests/golden/reference/CHECKED.txt)."""
+    import make_golden
+    for name in names or list(make_golden.CASES):
+        case = make_golden.CASES[name]
+        W, H = case[2], case[3]
+        if W % 16 or H % 8:
+            print(f"{name}: {W}x{H} does not fit the reference's 16x8 blocks (pathtracer.py:74) -- not runnable", flush=True)
+            continue
+        t = time.time()
+        sess = ReferenceSession(make_golden.config_of(case))
+        got = make_golden.run_case(sess, case)
+        want = np.load(os.path.join(HERE, name + ".npz"))
+        bad = {}
+        for key in want.files:
+            a, b = np.ascontiguousarray(got[key]), want[key]
+            same = (a.view(np.uint8) == b.view(np.uint8)).reshape(H, W, -1).all(-1)
+            if not same.all():
+                bad[key] = np.argwhere(~same).tolist()
+        undefined = np.argwhere(sess.undefined_px).tolist()
+        verdict = "every buffer equal, bit for bit" if not bad else f"DIFFERS: { {k: v[:6] for k, v in bad.items()} }"
+        print(f"{name}: {W}x{H}, {sum(s[1] for s in case[7] if s[0] == 'accumulate')} passes: {verdict}; pixels with a level-0 hit outside the grid: {undefined} "
+              f"({time.time() - t:.0f} s)", flush=True)
+
+
 def main(argv):
     import make_golden
+    if "--check-golden" in argv:
+        return check_golden([a for a in argv if not a.startswith("--")])
     libm = "--libm" in argv
     names = [a for a in argv if not a.startswith("--")] or list(CASES) + ["rays", "functions"]
     os.makedirs(OUT, exist_ok=True)
@@ -500,6 +533,7 @@ def main(argv):
             continue
         t = time.time()
         sess = ReferenceSession(make_golden.config_of(case), libm=libm)
+        sess.tables_given = len(case) > 8 and case[8][0] == "given"    # (then the LUT and the cloud ambient feed nothing)
         out = make_golden.run_case(sess, case)
         if sess.undefined_px.any():
             out["undefined_px"] = sess.undefined_px
