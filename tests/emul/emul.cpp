@@ -29,6 +29,7 @@ struct Emu {
     std::vector<float> mats, mats_x, sky_scat, sky_trans;
     std::vector<GrisGeo> gris_geo;
     std::vector<GrisSrc> gris_src;
+    std::vector<GrisTest> gris_tst;
     int buf0, buf1, own0, own1;
     size_t n;
     std::vector<f3> cbuf[2], color_s, color_d2, color_s2, gb_pos;
@@ -269,23 +270,30 @@ static int accumulate_g(Emu* c, int n_samples) {
             gb.color_d_out = c->color_d2.data(); gb.color_s_out = c->color_s2.data();
             gb.gb_normal = out.gb_normal; gb.gb_depth = out.gb_depth; gb.gb_mat = out.gb_mat;
             gb.res_in = c->res[0].data(); gb.res_out = c->res[1].data();
-            c->gris_geo.resize((size_t)(fp.row1 - fp.row0) * fp.W); c->gris_src.resize(c->gris_geo.size());
+            c->gris_geo.resize((size_t)(fp.row1 - fp.row0) * fp.W); c->gris_src.resize(c->gris_geo.size()); c->gris_tst.resize(c->gris_geo.size());
             if (c->mats_x.empty()) derive_materials(c);
-            gb.geo = c->gris_geo.data(); gb.src = c->gris_src.data(); gb.mats_x = c->mats_x.data();
+            gb.geo = c->gris_geo.data(); gb.src = c->gris_src.data(); gb.tst = c->gris_tst.data(); gb.mats_x = c->mats_x.data();
             for (int v = fp.row0; v < fp.row1; v++)
                 for (int u = 0; u < fp.W; u++) gris_prepare_pixel(fp, sc, gb, u, v);
             GlobalPyramid<G> P;
             P.p = sc.pyr;
             int g0 = c->own0 - 2 < c->buf0 ? c->buf0 : c->own0 - 2, g1 = c->own1 + 2 > c->buf1 ? c->buf1 : c->own1 + 2;
-            for (int v = g0; v < g1; v++)
-                for (int u = 0; u < fp.W; u++) {
-                    float cs[64];
-                    uint16_t off[32];
-                    for (int i = 0; i < 32; i++) gris_tap_cs(u, v, 0, i, cs);
-                    GrisTaps taps;
-                    taps.cs = cs; taps.off = off; taps.off_stride = 1;
-                    gris_pixel(fp, sc, P, gb, taps, u, v, 0, 24.0f, 32, 1, c->ts);
-                }
+            // VRT_EMU_GRIS_SPLIT: the pass as the GPU runs it, two kernels (every pixel's first half, then every pixel's second half)
+            const bool split = getenv("VRT_EMU_GRIS_SPLIT") != nullptr;
+            for (int phase = split ? 1 : 0; phase <= (split ? 3 : 0); phase++)      // split: classify (here 1), first half (2), second half (3)
+                for (int v = g0; v < g1; v++)
+                    for (int u = 0; u < fp.W; u++) {
+                        float cs[64];
+                        uint16_t off[32];
+                        for (int i = 0; i < 32; i++) gris_tap_cs(u, v, 0, i, cs);
+                        GrisTaps taps;
+                        taps.cs = cs; taps.off = off; taps.off_stride = 1;
+                        if (split && phase == 1) { gris_classify_pixel(fp, gb, taps, u, v, 24.0f, 32, c->ts); continue; }
+                        if (split) { if (phase == 2) gris_pixel<1>(fp, sc, P, gb, taps, u, v, 0, 24.0f, 32, 1, c->ts); else gris_pixel<2>(fp, sc, P, gb, taps, u, v, 0, 24.0f, 32, 1, c->ts); continue; }
+                        if (phase == 0) gris_pixel<0>(fp, sc, P, gb, taps, u, v, 0, 24.0f, 32, 1, c->ts);
+                        else if (phase == 1) gris_pixel<1>(fp, sc, P, gb, taps, u, v, 0, 24.0f, 32, 1, c->ts);
+                        else gris_pixel<2>(fp, sc, P, gb, taps, u, v, 0, 24.0f, 32, 1, c->ts);
+                    }
             cd = c->color_d2.data();
             cs = c->color_s2.data();
         } else if (getenv("VRT_EMU_POOL")) {

@@ -47,6 +47,16 @@ def test_emulated_device_code_reproduces_fixture(name):
     e.close()
 
 
+@pytest.mark.parametrize("name", sorted(n for n in mg.CASES if "restir" in n))
+def test_emulated_split_spatial_pass_reproduces_fixture(name, monkeypatch):
+    """The spatial-reuse pass as the GPU runs it -- two kernels, the first leaving the second its masks of accepted and of live taps
+    (vrt_restir.h) -- on the host build of the device code."""
+    monkeypatch.setenv("VRT_EMU_GRIS_SPLIT", "1")
+    e = emu.Emulated(mg.config_of(mg.CASES[name]))
+    check(e, name)
+    e.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("schedule", ["pool", "fused"])
 @pytest.mark.parametrize("name", sorted(mg.CASES))

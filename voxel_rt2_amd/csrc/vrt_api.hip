@@ -90,6 +90,7 @@ struct vrt_ctx {
     ReservoirRec* d_res_planes = nullptr;   // input reservoirs: VRT_MAX_FUSED planes, d_res[0] is the last of them
     GrisGeo* d_gris_geo = nullptr;   // per-pixel records of k_gris's prepare pass (vrt_restir.h)
     GrisSrc* d_gris_src = nullptr;
+    GrisTest* d_gris_tst = nullptr;
     float* d_mats_x = nullptr;       // [128][8] mat_derive() of every material row
     int cur = 0;      // g-buffer rotation: render writes [cur], temporal reads [prev_gb] as "prev"
     int prev_gb = VRT_GB_ROT - 1;  // the copy the most recent launch wrote
@@ -355,7 +356,7 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
         if (ok) c->d_res[0] = c->d_res_planes + (size_t)(VRT_MAX_FUSED - 1) * n;
     }
     if (cfg->use_restir) ok = ok && dalloc(&c->d_color_d2, n) == hipSuccess && dalloc(&c->d_color_s2, n) == hipSuccess &&
-                              dalloc(&c->d_gris_geo, n) == hipSuccess && dalloc(&c->d_gris_src, n) == hipSuccess;
+                              dalloc(&c->d_gris_geo, n) == hipSuccess && dalloc(&c->d_gris_src, n) == hipSuccess && dalloc(&c->d_gris_tst, n) == hipSuccess;
     ok = ok && dalloc(&c->d_mats_x, 128 * 8) == hipSuccess;
     if (cfg->sky_res > 0) {
         size_t ns = (size_t)cfg->sky_res * cfg->sky_res * 3;
@@ -422,7 +423,7 @@ void vrt_destroy(vrt_ctx* c) {
                     c->d_sky_trans, c->d_cloud_ambient, c->d_trans_lut, c->d_cloud_tex, c->d_cbuf[0], c->d_cbuf[1], c->d_spec_planes, c->d_color_d2,
                     c->d_color_s2, c->d_gb_pos, c->d_gb_normal[0], c->d_gb_normal[1], c->d_gb_depth[0], c->d_gb_depth[1],
                     c->d_gb_mat, c->d_refl_planes, c->d_gb_refl_f, c->d_hist_d[0], c->d_hist_d[1], c->d_hist_s[0], c->d_hist_s[1],
-                    c->d_ldr, c->d_ldr8, c->d_res[1], c->d_res_planes, c->d_multi_d, c->d_pool_scratch, c->d_gris_geo, c->d_gris_src, c->d_mats_x};
+                    c->d_ldr, c->d_ldr8, c->d_res[1], c->d_res_planes, c->d_multi_d, c->d_pool_scratch, c->d_gris_geo, c->d_gris_src, c->d_gris_tst, c->d_mats_x};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (c->stream && c->owns_stream) hipStreamDestroy(c->stream);
@@ -866,7 +867,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
                 gb.color_d_in = out.color_d + off; gb.color_s_in = out.color_s + off; gb.color_d_out = c->d_color_d2; gb.color_s_out = c->d_color_s2;
                 gb.gb_normal = out.gb_normal; gb.gb_depth = out.gb_depth; gb.gb_mat = out.gb_mat;
                 gb.res_in = out.reservoir + off; gb.res_out = c->d_res[1];
-                gb.geo = c->d_gris_geo; gb.src = c->d_gris_src; gb.mats_x = c->d_mats_x;
+                gb.geo = c->d_gris_geo; gb.src = c->d_gris_src; gb.tst = c->d_gris_tst; gb.mats_x = c->d_mats_x;
                 int g0 = c->own0 - 2 < c->buf0 ? c->buf0 : c->own0 - 2, g1 = c->own1 + 2 > c->buf1 ? c->buf1 : c->own1 + 2;
                 if (record(c, 2, &a, &b) != VRT_OK) return VRT_E_DEVICE;
                 HIP_TRY(hipEventRecord(a, c->stream));

@@ -677,6 +677,26 @@ __global__ __launch_bounds__(256, (PHASE == 1 ? VRT_GRIS_MIN_WAVES_A : PHASE == 
     if (INSTR) flush_stats(ts, sc.counters);
 }
 
+// split pass, before its two kernels: masks of accepted and of live taps per pixel (gris_classify_pixel).  Same tiling as k_gris:
+// a wave is one 8x8 tile of the tap-angle hash.
+template <bool INSTR>
+__global__ __launch_bounds__(256) void k_gris_classify(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r_first, int r1, int tiles_x, int band_w) {
+    __shared__ float s_cs[4][64];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bx = xcd * band_w + slot % band_w, by = slot / band_w;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int u = bx * 16 + (wave & 1) * 8 + (lane & 7);
+    const int v = r0 + by * 16 + (wave >> 1) * 8 + (lane >> 3);
+    if (lane < 32) gris_tap_cs(u, v, 0, lane, s_cs[wave]);
+    __syncthreads();
+    GrisTaps taps;
+    taps.cs = s_cs[wave]; taps.off = nullptr; taps.off_stride = 0;
+    TraceStats ts;
+    stats_zero(ts);
+    if (bx < tiles_x && u < fp.W && v >= r_first && v < r1) gris_classify_pixel(fp, gb, taps, u, v, 24.0f, 32, ts);
+    if (INSTR) flush_stats(ts, sc.counters);
+}
+
 // once per pixel of every row the launch holds: the records k_gris reads ~32 times per pixel (vrt_restir.h)
 __global__ __launch_bounds__(256) void k_gris_prepare(FrameParams fp, SceneData sc, GrisBuffers gb) {
     const int u = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -858,6 +878,8 @@ hipError_t launch_gris(hipStream_t st, int grid_res, bool instr, const FramePara
     const int tiles_x = (fp.W + 15) / 16, tiles_y = (r1 - ra + 15) / 16, band_w = (tiles_x + 7) / 8;
     dim3 g(8 * band_w * tiles_y), b(256);
 #if VRT_GRIS_SPLIT
+    if (instr) hipLaunchKernelGGL((k_gris_classify<true>), g, b, 0, st, fp, sc, gb, ra, r0, r1, tiles_x, band_w);
+    else hipLaunchKernelGGL((k_gris_classify<false>), g, b, 0, st, fp, sc, gb, ra, r0, r1, tiles_x, band_w);
     VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_gris<G, A, 1>), g, b, 0, st, fp, sc, gb, ra, r0, r1, tiles_x, band_w)));
     VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_gris<G, A, 2>), g, b, 0, st, fp, sc, gb, ra, r0, r1, tiles_x, band_w)));
 #else

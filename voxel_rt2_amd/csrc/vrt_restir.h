@@ -165,6 +165,21 @@ struct RcPre {
     MatColours col;      // mat_colours() of the reconnection vertex' material
     DirTerms inc, nee;   // dir_terms() of rc_incident_dir and rc_nee_dir at the reconnection vertex
 };
+// The Jacobian shift_sample() returns (out_jac), alone: :681-688 and :789-803 need the two primary vertices and three fields of the sample.
+VRT_DEV float shift_jacobian(f3 dst_pos, f3 dst_normal, f3 rc_pos, f3 rc_normal, float cached_jac) {
+    const bool escape = near_zero3(rc_normal);
+    const f3 to_rc = escape ? rc_pos : norm3(rc_pos - dst_pos);
+    float passed = 1.0f;
+    if (dot3(dst_normal, to_rc) < 1e-5f || (!escape && dot3(rc_normal, -to_rc) < 1e-5f)) passed = 0.0f;
+    float jac = 1.0f;
+    if (!escape) {
+        f3 dv = rc_pos - dst_pos;
+        jac = cached_jac;
+        jac *= dm_abs(dot3(norm3(dv), rc_normal)) / dot3(dv, dv);
+    }
+    if (jac < 0.0f || dm_isnan(jac) || dm_isinf(jac)) jac = 0.0f;
+    return jac * passed;
+}
 VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const float* mats_x, f3 dst_pos, const Surf& ds, const SurfShared& dsc,
                           const Reservoir& src, f3 rc_ty, f3 src_sky_t, const RcPre& pre, f3& out_d, f3& out_s, float& out_jac, TraceStats& ts) {
     const bool escape = near_zero3(src.z.rc_normal);
@@ -272,9 +287,18 @@ struct alignas(16) GrisSrc {
     float inc_pd, nee_pd; uint32_t pad4, pad5;
 };
 
+// What the classify kernel reads of a pixel each time it is somebody's tap: 48 bytes of its own, because read out of the two records
+// above (16 of 128 bytes, 32 of 224) every tap drags two whole cache lines through an L2 that the tap windows of the waves in flight
+// then do not fit (measured: 2.5 ms for the kernel; with this record the windows are a few MB per XCD).
+struct alignas(16) GrisTest {
+    f3 n; float dist;        // = GrisGeo: the geometric test (:912)
+    f3 rc_pos; float jac;    // = GrisSrc: what shift_jacobian() needs of the sample
+    f3 rc_normal; float M;
+};
 struct GrisBuffers {
     GrisGeo* geo;            // [rows of the launch][W], written by the prepare pass
     GrisSrc* src;
+    GrisTest* tst;
     const float* mats_x;     // [128][8]: mat_derive() of every material id
     const f3* color_d_in;
     const f3* color_s_in;
@@ -336,6 +360,9 @@ VRT_DEV void gris_prepare_pixel(const FrameParams& fp, const SceneData& sc, cons
         s.pad4 = 0u; s.pad5 = 0u;
     }
     gb.src[idx] = s;
+    GrisTest t;
+    t.n = g.n; t.dist = g.dist; t.rc_pos = s.rc_pos; t.jac = s.jac; t.rc_normal = s.rc_normal; t.M = g.M;
+    gb.tst[idx] = t;
 }
 VRT_DEV void gris_load_src(Reservoir& r, f3& rc_ty, f3& sky_t, RcPre& pre, const GrisSrc& s) {
     r.z.F = s.F; r.M = s.M; r.z.rc_pos = s.rc_pos; r.weight = s.weight; r.z.rc_normal = s.rc_normal; r.z.jac = s.jac;
@@ -377,6 +404,41 @@ VRT_DEV bool gris_tap(const FrameParams& fp, const GrisTaps& taps, int u, int v,
     tx = u + ox; ty = v + oy;
     if (ox == 0 && oy == 0) return false;
     return !(tx < 0 || ty < 0 || tx >= fp.W || ty >= fp.H);
+}
+
+// Split pass, before its two kernels: which taps pass the geometric test (:883-912, the mask both kernels walk), and which of
+// those carry a sample whose shift into this pixel's domain has a Jacobian that is not zero (see the resampling loop of
+// gris_pixel).  Needs 16 + 32 bytes per tap and no BSDF: a kernel of 8 waves per SIMD instead of 3.
+VRT_DEV void gris_classify_pixel(const FrameParams& fp, const GrisBuffers& gb, const GrisTaps& taps, int u, int v, float max_radius, int max_taps,
+                                 TraceStats& ts) {
+    const int idx = (v - fp.row0) * fp.W + u;
+    if (outside_render_area(fp, (float)u, (float)v)) return;
+    dm_rng rng = dm_rng_init(fp.seed, fp.frame, (uint32_t)(v * fp.W + u), 1u);
+    (void)dm_rng_f32(&rng);  // start_index draw (:827), value unused
+    const float radius_shift = dm_rng_f32(&rng);
+    const GrisGeo* cg = &gb.geo[idx];
+    const f3 cx1 = cg->x1, cn1 = cg->n;
+    const float cdist = cg->dist;
+    if (near_zero3(cx1)) return;
+    unsigned accepted = 0u, live = 0u;
+    float dead_M = 0.0f;
+    for (int i = 0; i < max_taps; i++) {
+        int tx, ty;
+        if (!gris_tap(fp, taps, u, v, i, radius_shift, max_radius, max_taps, tx, ty)) continue;
+        const GrisTest* nt = &gb.tst[(ty - fp.row0) * fp.W + tx];
+        if (dm_abs(nt->dist - cdist) > 0.1f * cdist || dot3(cn1, nt->n) < 0.5f) continue;  // :912
+        accepted |= 1u << i;
+        const f3 rc_normal = nt->rc_normal;
+        if (shift_jacobian(cx1, cn1, nt->rc_pos, rc_normal, nt->jac) != 0.0f) live |= 1u << i;
+        else {
+            dead_M += nt->M;
+            // (the reference still looks the sky's transmittance up for such a shift, :770-772: counted for instrumented launches)
+            if (fp.use_sky == 1 && !near_zero3(rc_normal) && !near_zero3(gb.src[(ty - fp.row0) * fp.W + tx].rc_nee_dir)) ts.sky_lookups += 1u;
+        }
+    }
+    gb.geo[idx].pad = accepted;
+    gb.src[idx].pad0 = live;
+    gb.src[idx].pad1 = dm_f2u(dead_M);
 }
 
 // pathtracer.py:815-989, called as spatial_GRIS(0, 24.0, 32, 1) (:1313)
@@ -432,8 +494,9 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     // each pixel's OWN accepted taps (ascending, so the order of sums and draws is the reference's): a wave runs as many
     // trips as its busiest pixel accepted taps instead of all 32 with the rejected pixels' lanes idle.
     unsigned accepted = 0u;  // max_taps <= 32
+    if (PHASE == 1) accepted = cg.pad;    // (split pass: from gris_classify_pixel)
     if (PHASE == 2) { accepted = cg.pad; canonical_mis = dm_u2f(cg.pad3); }
-    for (int i = 0; PHASE != 2 && i < max_taps; i++) {
+    for (int i = 0; PHASE == 0 && i < max_taps; i++) {
         int tx, ty;
         if (!gris_tap(fp, taps, u, v, i, radius_shift, max_radius, max_taps, tx, ty)) continue;
         taps.off[i * taps.off_stride] = (uint16_t)((tx - u + 128) | ((ty - v + 128) << 8));  // |offset| <= max_radius < 128
@@ -445,8 +508,12 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     }
     for (unsigned m = (PHASE == 2) ? 0u : accepted; m != 0u; m &= m - 1u) {
         const int i = __builtin_ctz(m);
-        const int packed = taps.off[i * taps.off_stride];
-        const int tx = u + (packed & 255) - 128, ty = v + (packed >> 8) - 128;
+        int tx, ty;
+        if (PHASE == 1) (void)gris_tap(fp, taps, u, v, i, radius_shift, max_radius, max_taps, tx, ty);
+        else {
+            const int packed = taps.off[i * taps.off_stride];
+            tx = u + (packed & 255) - 128; ty = v + (packed >> 8) - 128;
+        }
         const GrisGeo ng = gb.geo[(ty - fp.row0) * fp.W + tx];
         const float nb_M = ng.M;
         const int nmat_id = (int)(ng.mat & 255u);
@@ -468,7 +535,6 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     // the second the centre's shading point and the output reservoir -- neither needs the other's, so the shading point is
     // built only now and the centre's sample is read again after the second loop instead of being kept across it.
     if (PHASE == 1) {   // what the second kernel needs of the first
-        gb.geo[idx].pad = accepted;
         gb.geo[idx].pad3 = dm_f2u(canonical_mis);
         return;
     }
@@ -479,13 +545,48 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     surf_set(cds, cmat, load_mat_derived(gb.mats_x, cmat_id), cn1, cg.v, cross3(cn1, cg.ty), cg.ty);
     SurfShared cdsc;   // destination of every neighbour's sample, whatever its lobe: from the prepare pass (= surf_shared(cds, 1, 1, 1))
     cdsc.lambert = cg.lambert; cdsc.sheen_col = cg.sheen_col; cdsc.spec_col = cg.spec_col; cdsc.fv = cg.fv; cdsc.g_v = cg.g_v; cdsc.gc_v = cg.gc_v;
-    for (unsigned m = accepted; m != 0u; m &= m - 1u) {
-        const int i = __builtin_ctz(m);
-        int tx, ty;
-        if (PHASE == 2) (void)gris_tap(fp, taps, u, v, i, radius_shift, max_radius, max_taps, tx, ty);   // (the first kernel's table of offsets is gone)
-        else {
-            const int packed = taps.off[i * taps.off_stride];
-            tx = u + (packed & 255) - 128; ty = v + (packed >> 8) - 128;
+    // A shift whose Jacobian comes out zero -- the sample's reconnection vertex lies behind the destination's horizon or faces away
+    // from it (:684-688), the usual fate of a stored escape sample, whose zero normal comes back from its 8-bit code as (0, 0, -1)
+    // -- leaves no trace beyond the two counters: p_hat / 0 is inf or NaN, so the MIS weight is inf / inf = NaN -> 0 (:941-943) and
+    // the merge weight w * p_hat * 0 * 0 is 0 or NaN, never > 0: no draw, no selection, M += and valid += only (reservoir.py:78-85).
+    // Two shifts in three (nine in ten at small frame sizes) end that way in a scene open to the sky.  The Jacobian needs 32 bytes
+    // of the sample and ~100 instructions (shift_jacobian: the same expressions as shift_sample, so the same bits):
+    //  * split pass: a small kernel of its own (gris_classify_pixel, many waves per SIMD) works it out for every tap and leaves the
+    //    mask of live taps and the summed M of the dead ones in the pixel's GrisSrc record (pad0, pad1); this kernel then runs the
+    //    BSDF work for live taps only -- a wave's trips are its busiest pixel's LIVE taps.  (M counts merged samples: 1 or 2 out
+    //    of the render pass, whole numbers far below 2^24, so their sum does not depend on the order.  Worked out inside the first
+    //    kernel's tap loop instead, the same test cost that kernel 0.78 ms for the 0.9 ms it saves here.)
+    //  * whole pass: each lane runs through its dead taps before the wave meets at the BSDF work.
+    // (The first loop cannot drop its own dead shifts: its weight is 0 / X only if the integrand it multiplies by 0 is finite.)
+    if (PHASE == 2) {
+        const unsigned live = gb.src[idx].pad0;
+        outr.M = dm_u2f(gb.src[idx].pad1);
+        valid = __builtin_popcount(accepted & ~live);
+        accepted = live;
+    }
+    for (unsigned m = accepted; m != 0u;) {
+        int i, tx, ty;
+        if (PHASE == 2) {
+            i = __builtin_ctz(m);
+            m &= m - 1u;
+            (void)gris_tap(fp, taps, u, v, i, radius_shift, max_radius, max_taps, tx, ty);   // (the first kernel's table of offsets is gone)
+        } else {
+            bool live;
+            do {
+                i = __builtin_ctz(m);
+                m &= m - 1u;
+                const int packed = taps.off[i * taps.off_stride];
+                tx = u + (packed & 255) - 128; ty = v + (packed >> 8) - 128;
+                const GrisSrc* sp = &gb.src[(ty - fp.row0) * fp.W + tx];
+                live = shift_jacobian(cx1, cn1, sp->rc_pos, sp->rc_normal, sp->jac) != 0.0f;
+                if (!live) {
+                    outr.M += sp->M;
+                    valid += 1;
+                    // (the reference still looks the sky's transmittance up for such a shift, :770-772: counted for instrumented launches)
+                    if (fp.use_sky == 1 && !near_zero3(sp->rc_normal) && !near_zero3(sp->rc_nee_dir)) ts.sky_lookups += 1u;
+                }
+            } while (!live && m != 0u);
+            if (!live) break;
         }
         Reservoir nb;
         f3 nb_rc_ty, nb_sky_t;
