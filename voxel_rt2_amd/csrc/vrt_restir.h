@@ -422,18 +422,30 @@ VRT_DEV void gris_classify_pixel(const FrameParams& fp, const GrisBuffers& gb, c
     if (near_zero3(cx1)) return;
     unsigned accepted = 0u, live = 0u;
     float dead_M = 0.0f;
-    for (int i = 0; i < max_taps; i++) {
-        int tx, ty;
-        if (!gris_tap(fp, taps, u, v, i, radius_shift, max_radius, max_taps, tx, ty)) continue;
-        const GrisTest* nt = &gb.tst[(ty - fp.row0) * fp.W + tx];
-        if (dm_abs(nt->dist - cdist) > 0.1f * cdist || dot3(cn1, nt->n) < 0.5f) continue;  // :912
-        accepted |= 1u << i;
-        const f3 rc_normal = nt->rc_normal;
-        if (shift_jacobian(cx1, cn1, nt->rc_pos, rc_normal, nt->jac) != 0.0f) live |= 1u << i;
-        else {
-            dead_M += nt->M;
-            // (the reference still looks the sky's transmittance up for such a shift, :770-772: counted for instrumented launches)
-            if (fp.use_sky == 1 && !near_zero3(rc_normal) && !near_zero3(gb.src[(ty - fp.row0) * fp.W + tx].rc_nee_dir)) ts.sky_lookups += 1u;
+    // four taps at a time, their records fetched before any is looked at: the loop is a chain of dependent cache misses otherwise
+    // (a tap outside the image fetches the pixel's own record, which is not used)
+    for (int i0 = 0; i0 < max_taps; i0 += 4) {
+        GrisTest rec[4];
+        int at[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int tx, ty;
+            const bool in = i0 + k < max_taps && gris_tap(fp, taps, u, v, i0 + k, radius_shift, max_radius, max_taps, tx, ty);
+            at[k] = in ? (ty - fp.row0) * fp.W + tx : -1;
+            rec[k] = gb.tst[in ? at[k] : idx];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (at[k] < 0) continue;
+            const GrisTest& nt = rec[k];
+            if (dm_abs(nt.dist - cdist) > 0.1f * cdist || dot3(cn1, nt.n) < 0.5f) continue;  // :912
+            accepted |= 1u << (i0 + k);
+            if (shift_jacobian(cx1, cn1, nt.rc_pos, nt.rc_normal, nt.jac) != 0.0f) live |= 1u << (i0 + k);
+            else {
+                dead_M += nt.M;
+                // (the reference still looks the sky's transmittance up for such a shift, :770-772: counted for instrumented launches)
+                if (fp.use_sky == 1 && !near_zero3(nt.rc_normal) && !near_zero3(gb.src[at[k]].rc_nee_dir)) ts.sky_lookups += 1u;
+            }
         }
     }
     gb.geo[idx].pad = accepted;
