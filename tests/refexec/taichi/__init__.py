@@ -53,8 +53,15 @@ def _norm(x):
     return x
 
 
+_scope = [0]    # > 0 inside a ti.kernel / ti.func.  In Python scope Taichi's vectors hold plain Python numbers and their arithmetic is
+                # Python's (double): Atmos.__init__ derives its coefficients that way (atmos.py:36-50) and they are rounded to f32
+                # once, where a kernel uses them
+
+
 def _typed(x):
     """A Python number entering a vector / a typed slot."""
+    if _scope[0] == 0 and isinstance(x, (_b.int, _b.float)):
+        return x
     if isinstance(x, _b.bool):
         return _np.int32(x)
     if isinstance(x, _b.int):
@@ -168,7 +175,9 @@ class Vector:
                 out.extend(_typed(y) for y in x)
             else:
                 out.append(_typed(x))
-        if dt is not None:
+        if _scope[0] == 0 and _b.all(isinstance(x, (_b.int, _b.float)) for x in out):
+            pass    # Python scope, Python numbers: kept as they are
+        elif dt is not None:
             out = [_cast1(x, dt) for x in out]
         elif any(_is_float(x) for x in out):   # a vector has ONE element type: float wins
             out = [x if _is_float(x) else _np.float32(x) for x in out]
@@ -994,7 +1003,12 @@ def _dsl(fn):
             if isinstance(t, _Template) or name == "self":
                 continue
             bound[n] = _arg(a, t)
-        return raw(*bound, **{key: (v if isinstance(ann.get(key), _Template) else _arg(v, ann.get(key))) for key, v in kwargs.items()})
+        kw = {key: (v if isinstance(ann.get(key), _Template) else _arg(v, ann.get(key))) for key, v in kwargs.items()}
+        _scope[0] += 1
+        try:
+            return raw(*bound, **kw)
+        finally:
+            _scope[0] -= 1
     wrapper.__name__ = fn.__name__
     wrapper.__wrapped__ = fn
     return wrapper
@@ -1053,6 +1067,8 @@ class _VecType:
             flat = flat * self.n
         if len(flat) != self.n:
             raise ValueError(f"vector({self.n}) got {len(flat)} components")
+        if _scope[0] == 0:
+            return Vector._new([x if isinstance(x, (_b.int, _b.float)) else _cast1(x, self.dt) for x in flat])
         return Vector._new([_cast1(x, self.dt) for x in flat])
 
     def zero(self): return Vector._new([self.dt(0)] * self.n)
