@@ -210,10 +210,10 @@ def run_secondary(lib, case, counters):
     ms = {k: st[f"{k}_ms"] / max(st[f"{k}_launches"], 1) for k in ("render", "gris", "temporal")}
     per_launch = st["path_samples"] / max(st["render_launches"], 1)
     if case.get("restir"):
-        # per sample: k_render<restir> + k_gris_prepare + k_gris + k_temporal; the spatial-reuse pass dominates
+        # per sample: k_render<restir> + k_gris_prepare + k_gris_classify + k_gris (two kernels) + k_temporal; the spatial-reuse pass dominates
         kernel, kms, units = "k_gris", ms["gris"], px
         b_ref = b_timed = float(GRIS_BYTES_PER_PIXEL)
-        note = ("dominant kernel of this config: the ReSTIR spatial-reuse pass (k_gris_prepare + k_gris, timed together); unit = one pixel of "
+        note = ("dominant kernel of this config: the ReSTIR spatial-reuse pass (k_gris_prepare + k_gris_classify + k_gris<.,.,1> + k_gris<.,.,2>, timed together); unit = one pixel of "
                 "one pass; bytes = the reference algorithm's reads/writes per pixel (SURVEY.md 8 a13); the pass is VALU bound (DESIGN.md 4)")
     else:
         kernel, kms, units = "k_render_pool", ms["render"], per_launch

@@ -65,8 +65,10 @@ def main():
                 k, v = pick(m, "vrt::k_render_pool_dense<", 1)
             if v and short == "k_gris":
                 # the spatial-reuse pass runs as two kernels (template argument 3 = 1, 2: vrt_restir.h): one entry, their counters summed
+                # (round 3: behind a third, k_gris_classify<INSTR>, that hands them their masks of accepted and of live taps)
                 halves = [(kk, vv) for kk, vv in m.items() if kk.replace("void ", "").startswith(prefix)
                           and [a_.strip() for a_ in kk.split("<")[1].rstrip(">").split(",")][ia] != "true"]
+                halves += [(kk, vv) for kk, vv in m.items() if kk.replace("void ", "").startswith("vrt::k_gris_classify<false>")]
                 if len(halves) > 1:
                     names = sorted(kk for kk, _ in halves)
                     summed = {}
