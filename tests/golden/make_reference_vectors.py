@@ -23,6 +23,8 @@ What these vectors pin: the oracle (and through it the HIP library) against the 
 What they cannot pin: Taichi's code generation itself (fast-math reassociation, its own elementary functions).
 
     python tests/golden/make_reference_vectors.py [case ...]      # from the repo root; ~4 min per case (2 M-voxel Python loops)
+    ... --verify [case ...]     runs the cases again and compares with the committed files; --check-golden runs make_golden.py's cases
+    ... --libm [case ...]       numpy's elementary functions instead of the contract's: reports the drift
 """
 import ctypes as C
 import os
@@ -530,7 +532,7 @@ def main(argv):
             function_vectors(os.path.join(OUT, "functions.npz"))
     for name in names:
         case = CASES[name]
-        if os.path.exists(os.path.join(OUT, name + ".npz")) and not libm and "--force" not in argv:
+        if os.path.exists(os.path.join(OUT, name + ".npz")) and not libm and "--force" not in argv and "--verify" not in argv:
             print(name, "exists (--force rewrites it)")
             continue
         t = time.time()
@@ -541,6 +543,11 @@ def main(argv):
             out["undefined_px"] = sess.undefined_px
             print(f"  {int(sess.undefined_px.sum())} pixels hit a 'voxel' outside the grid (a set level-0 bit read through an index that left the grid): {np.argwhere(sess.undefined_px).tolist()}")
         path = os.path.join(OUT, name + ".npz")
+        if "--verify" in argv:     # run again, compare with the committed file, write nothing
+            want = np.load(path)
+            same = sorted(want.files) == sorted(out) and all(np.array_equal(np.ascontiguousarray(out[k]).view(np.uint8), want[k].view(np.uint8)) for k in want.files)
+            print(f"{name}: the committed fixture is {'reproduced' if same else 'NOT reproduced'} ({time.time() - t:.0f} s)", flush=True)
+            continue
         if libm:
             want = np.load(path)
             for key in ("hdr", "ldr"):

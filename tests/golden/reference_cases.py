@@ -10,4 +10,7 @@ CASES = {
     "ref_dense_32x16_d3": ("dense", 12345, 32, 16, 3, 3, False, [("accumulate", 1)]),
     # the physical sky's LOOKUP (atmos.py:94-131: jittered direction, wrapped bilinear fetch; NEE and shift() transmittance) on given tables
     "ref_s6_sky_lookup_32x16_d4": ("s6", 0, 32, 16, 4, 23, True, [("accumulate", 2)], ("given", 64, 5)),
+    # the sky / cloud PRECOMPUTE (atmos.py: the 256x128 transmittance LUT, the cloud ambient, 3 cloud passes, 4 slices of the two skybox tables)
+    # at 8 x 8 texels -- the table size is an instance attribute of Atmos, set from outside (3840 in the reference: hours of Python per column)
+    "ref_s6_sky_precompute_16x8_d3": ("s6", 0, 16, 8, 3, 21, False, [("accumulate", 1)], (8, 3, 4)),
 }
