@@ -1,20 +1,27 @@
-"""tests/refexec/taichi -- TEST INFRASTRUCTURE: a host-side emulation of the part of the Taichi DSL that the reference's
-renderer modules use, so that the reference's OWN SOURCE FILES (/root/reference/renderer/{math_utils,raytracer,bsdf,reservoir,
-space_transformations}.py, imported from where they lie, never copied) execute as plain Python and can generate golden vectors
-for the oracle (tests/golden/make_reference_vectors.py).  This is NOT Taichi and it is not the product's `taichi/` shim (which
-only runs the example scripts' voxel-authoring kernels): it is one reading of Taichi's documented semantics (SURVEY.md
-Appendix A) --
+"""tests/refexec/taichi -- TEST INFRASTRUCTURE: a host-side emulation of the part of the Taichi DSL that the reference's renderer
+modules use, so that the reference's OWN SOURCE FILES (/root/reference/renderer/*.py, imported from where they lie, never copied)
+execute as plain Python and can generate golden vectors for the oracle (tests/golden/make_reference_vectors.py).  This is NOT
+Taichi and it is not the product's `taichi/` shim (which only runs the example scripts' voxel-authoring kernels): it is one
+reading of Taichi's documented semantics --
 
-  * default_fp = f32, default_ip = i32: scalars are numpy float32 / int32 values, every operation rounds to binary32 (numpy
-    scalar arithmetic, no contraction); Python-level constants stay Python floats until they meet a typed value;
-  * vectors / matrices / structs have VALUE semantics: `a = b` copies (an AST pass over every @ti.func / @ti.kernel body
-    rewrites plain assignments), arguments are passed by value unless annotated ti.template();
-  * ti.cast(float -> int) truncates; casts to f16 round to nearest even (numpy float16); u32 arithmetic wraps;
-  * v.normalized() = v * (1 / sqrt(sum of squares)), sums left to right; mat3(a, b, c) stacks rows;
-  * ti.random() comes from a sequence the caller injects (set_random_source), so a sampler can be fed the very numbers
-    the oracle's stream produces;
-  * reads past the end of a 1-D field give 0 and writes grow it (release-mode Taichi does not check bounds; the reference's
-    LOD base formula, raytracer.py:32, indexes past its own allocation).
+  * @ti.func / @ti.kernel bodies are re-compiled through an AST pass (_Scoping): every binary operator goes through Taichi's type
+    promotion (_sbin: f32 * i32 is an f32 product, not numpy's float64; a Python number is a compile-time constant that takes the
+    type of the typed operand it meets; two Python numbers stay Python numbers), every assignment through _assign (the first one
+    fixes a variable's type, later ones convert to it; vectors / matrices / structs are copied: value semantics), arguments are
+    passed by value except ti.template() parameters, which the callee may assign to (_BYREF: _trace_sdf, _trace_voxel);
+  * default_fp = f32, default_ip = i32; ti.cast(float -> int) truncates, to f16 rounds to nearest even; u32 arithmetic wraps;
+  * in PYTHON scope (outside kernels) vectors hold Python numbers and compute in double, as Taichi's do (Atmos.__init__'s
+    coefficients): they are rounded to f32 once, where a kernel uses them (_scope);
+  * v.normalized() = v * (1 / sqrt(sum of squares)), sums left to right; mat3(a, b, c) stacks rows; a constant whole-number
+    power is repeated multiplication by squaring (Taichi's algebraic simplification); ti.max / ti.min are maxnum / minnum;
+  * fields: dense, blocked (ti.root.dense(...).dense(...).place) and offset layouts, vector / matrix / struct fields, 0-d fields
+    through [None]; rgba8 / rgba32f textures (unorm8 store rounds to nearest, fetch returns byte / 255);
+  * the outermost for of a kernel over a field or an ndrange is a PARALLEL loop (_parallel): an iteration sees the value an
+    element had before the loop wherever another iteration has written it meanwhile;
+  * what Taichi leaves undefined is the CALLER's to supply: ti.random() (set_random_source: receives the index of the running
+    parallel iteration), the elementary functions (set_elementary; numpy's by default), reads outside a field
+    (set_out_of_bounds_reads: "clamp" / "zero" / "error", per field); reads past the end of a 1-D field give 0 and writes grow
+    it (the reference's LOD base formula, raytracer.py:32, indexes past its own allocation).
 
 What the vectors pin: the oracle against the reference's source text executed under these semantics -- not against Taichi's
 code generation (fast-math, its own sin / cos / pow), which stays unobservable here.
