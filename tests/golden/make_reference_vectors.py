@@ -479,6 +479,16 @@ def function_vectors(path, n=300, seed=9):
         q = reservoir(np.concatenate([row[:21], [1.0, 1.0]]).astype(np.float32))
         d, sp, jac = r.shift(V(dst_pos[k]), V(dst_n[k]), material(dst_mat[k]), V(src_pos[k]), V(dst_n[k]), material(dst_mat[k]), q)
         out["shift_out"][k] = d.to_list() + sp.to_list() + [jac]
+    # the skybox parameterisation (atmos.py:428-455) at the table size of the sky-lookup case
+    import make_golden as mg2
+    sky_case = ("s6", 0, 16, 8, 2, 0, False, [], ("given", 64, 5))
+    sky = ReferenceSession(mg2.config_of(sky_case))
+    dirs = np.concatenate([unit(300), np.eye(3, dtype=np.float32), -np.eye(3, dtype=np.float32)])
+    out["sky_dir"] = dirs
+    out["sky_uv"] = np.array([sky.r.atmos.project_sky(V(d)).to_list() for d in dirs], np.float32)
+    uv = rng.uniform(0.0, 1.0, (300, 2)).astype(np.float32)
+    out["sky_uv_in"] = uv
+    out["sky_dir_out"] = np.array([sky.r.atmos.unproject_sky(V(t)).to_list() for t in uv], np.float32)
     np.savez_compressed(path, **out)
     print(os.path.basename(path), {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.shape}, flush=True)
 

@@ -174,3 +174,13 @@ def test_oracle_functions_equal_reference_source():
         zero_jac += out[6] == 0.0
     assert 10 < zero_jac < len(v["shift_out"]) - 10      # both rejected and accepted shifts
     o.close()
+    o = orc.Oracle(host.make_config(16, 8, max_depth=2, sky_res=64), threads=1)     # project_sky / unproject_sky (atmos.py:428-455)
+    for k in range(len(v["sky_dir"])):
+        out = np.zeros(2, np.float32)
+        L.orc_unit_project_sky(C.c_void_p(o._ctx), f(np.ascontiguousarray(v["sky_dir"][k])), f(out))
+        assert _same(out, v["sky_uv"][k]), ("project_sky", k, out, v["sky_uv"][k])
+    for k in range(len(v["sky_uv_in"])):
+        out = np.zeros(3, np.float32)
+        L.orc_unit_unproject_sky(C.c_void_p(o._ctx), f(np.ascontiguousarray(v["sky_uv_in"][k])), f(out))
+        assert _same(out, v["sky_dir_out"][k]), ("unproject_sky", k)
+    o.close()
