@@ -40,7 +40,7 @@ sys.path[:0] = [os.path.join(ROOT, "tests", "refexec"), REFERENCE, ROOT, os.path
 import numpy as np  # noqa: E402
 import taichi  # noqa: E402,F401   (tests/refexec/taichi, before anything puts the repo root -- and the product's DSL shim -- first)
 
-from reference_cases import CASES  # noqa: E402
+from reference_cases import ALL_CASES as CASES  # noqa: E402
 
 
 _PREPARED = {}
