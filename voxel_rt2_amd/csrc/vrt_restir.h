@@ -408,7 +408,7 @@ VRT_DEV bool gris_tap(const FrameParams& fp, const GrisTaps& taps, int u, int v,
 
 // Split pass, before its two kernels: which taps pass the geometric test (:883-912, the mask both kernels walk), and which of
 // those carry a sample whose shift into this pixel's domain has a Jacobian that is not zero (see the resampling loop of
-// gris_pixel).  Needs 16 + 32 bytes per tap and no BSDF: a kernel of 8 waves per SIMD instead of 3.
+// gris_pixel).  Needs one 48-byte record per tap and no BSDF: a kernel of 6 waves per SIMD instead of 3.
 VRT_DEV void gris_classify_pixel(const FrameParams& fp, const GrisBuffers& gb, const GrisTaps& taps, int u, int v, float max_radius, int max_taps,
                                  TraceStats& ts) {
     const int idx = (v - fp.row0) * fp.W + u;
@@ -454,8 +454,8 @@ VRT_DEV void gris_classify_pixel(const FrameParams& fp, const GrisBuffers& gb, c
 }
 
 // pathtracer.py:815-989, called as spatial_GRIS(0, 24.0, 32, 1) (:1313)
-// PHASE 0: the whole pass.  PHASE 1 / 2: the pass as two kernels -- the tap test and the canonical MIS weight (first two
-// loops), which leave the mask of accepted taps and the weight in the pixel's own GrisGeo record (pad, pad3: nobody else reads
+// PHASE 0: the whole pass.  PHASE 1 / 2: the pass as two kernels behind gris_classify_pixel, which leaves them the mask of
+// accepted taps in the pixel's own GrisGeo record (pad) -- the canonical MIS weight (second loop), left in pad3 (nobody else reads
 // those words); then the resampling loop and everything after it.  Each half carries only its own loop invariants (the
 // centre's sample in the first, its shading point and the output reservoir in the second), which is what lets each fit the
 // 168 registers of a third wave per SIMD (the whole pass needs about 250).  Same arithmetic in the same order.
