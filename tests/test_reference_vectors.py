@@ -78,10 +78,6 @@ def test_emulated_device_code_equals_reference_source(name):
 def test_gpu_equals_reference_source(name, schedule, monkeypatch):
     from voxel_rt2_amd import _lib
     from voxel_rt2_amd._session import NativeSession
-    if len(CASES[name]) > 8 and CASES[name][8][0] != "given" and CASES[name][8][0] < 32:
-        pytest.skip("the library's sky tables start at 32 x 32 (vrt_create): 1 024 texels are half a day of the reference's atmos.py in Python.  "
-                    "The oracle takes this case, and the library equals the oracle's tables at 32..96 and at 3840 (tests/test_gpu_parity.py, "
-                    "tests/test_gpu_fullsize.py): the per-texel code does not depend on the table size")
     monkeypatch.setenv("VRT_RENDER", schedule)
     g = NativeSession(_lib.load(), "vrt_", mg.config_of(CASES[name]))
     check(g, name)

@@ -306,7 +306,7 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
     if (cfg->grid_res != 128 && cfg->grid_res != 256) { fail(VRT_E_INVALID, "grid_res must be 128 (pathtracer.py:83) or 256"); return nullptr; }
     if (cfg->width <= 0 || cfg->height <= 0 || cfg->width > 16384 || cfg->height > 16384) { fail(VRT_E_INVALID, "bad image size"); return nullptr; }
     if (cfg->max_depth < 1 || cfg->max_depth > 64) { fail(VRT_E_INVALID, "max_depth must be in 1..64"); return nullptr; }
-    if (cfg->sky_res < 0 || cfg->sky_res > 8192 || (cfg->sky_res > 0 && cfg->sky_res < 32)) { fail(VRT_E_INVALID, "sky_res must be 0 or 32..8192"); return nullptr; }
+    if (cfg->sky_res < 0 || cfg->sky_res > 8192 || (cfg->sky_res > 0 && cfg->sky_res < 4)) { fail(VRT_E_INVALID, "sky_res must be 0 or 4..8192"); return nullptr; }
     if (cfg->dx != 2.0f / (float)cfg->grid_res) { fail(VRT_E_INVALID, "dx must be 2 / grid_res: 1/64 at 128 (scene.py:11), 1/128 at 256 -- the grid spans the world box [-1, 1]^3"); return nullptr; }
     int own0 = 0, own1 = cfg->height;
     if (cfg->row_end > cfg->row_begin) {
