@@ -8,6 +8,9 @@ ALL_CASES = {
     "ref_sunlit_moving_32x16_d4": ("sunlit", 0, 32, 16, 4, 9, False, [("accumulate", 2), ("end_frame",), ("move", 0.45), ("accumulate", 1),
                                                                         ("end_frame",), ("still", 3), ("accumulate", 1)]),
     "ref_dense_32x16_d3": ("dense", 12345, 32, 16, 3, 3, False, [("accumulate", 1)]),
+    # ReSTIR through a camera move: spatial reuse on the half-resolution pass, albedo demodulation (pathtracer.py:981-982), Catmull-Rom history
+    "ref_sunlit_restir_moving_32x24_d4": ("sunlit", 0, 32, 24, 4, 17, True, [("accumulate", 2), ("end_frame",), ("move", 0.44), ("accumulate", 1),
+                                                                               ("end_frame",), ("still", 3), ("accumulate", 2)]),
     # the physical sky's LOOKUP (atmos.py:94-131: jittered direction, wrapped bilinear fetch; NEE and shift() transmittance) on given tables
     "ref_s6_sky_lookup_32x16_d4": ("s6", 0, 32, 16, 4, 23, True, [("accumulate", 2)], ("given", 64, 5)),
     # the sky / cloud PRECOMPUTE (atmos.py: the 256x128 transmittance LUT, the cloud ambient, 3 cloud passes, 4 slices of the two skybox tables)
