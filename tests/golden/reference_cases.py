@@ -11,6 +11,8 @@ ALL_CASES = {
     # ReSTIR through a camera move: spatial reuse on the half-resolution pass, albedo demodulation (pathtracer.py:981-982), Catmull-Rom history
     "ref_sunlit_restir_moving_32x24_d4": ("sunlit", 0, 32, 24, 4, 17, True, [("accumulate", 2), ("end_frame",), ("move", 0.44), ("accumulate", 1),
                                                                                ("end_frame",), ("still", 3), ("accumulate", 2)]),
+    # the example-6-style scene (eleven materials of the CSV, a small sun, no voxel edges) at six bounces, without its sky
+    "ref_s6_plain_48x24_d6": ("s6", 0, 48, 24, 6, 29, False, [("accumulate", 3)]),
     # the physical sky's LOOKUP (atmos.py:94-131: jittered direction, wrapped bilinear fetch; NEE and shift() transmittance) on given tables
     "ref_s6_sky_lookup_32x16_d4": ("s6", 0, 32, 16, 4, 23, True, [("accumulate", 2)], ("given", 64, 5)),
     # the sky / cloud PRECOMPUTE (atmos.py: the 256x128 transmittance LUT, the cloud ambient, 3 cloud passes, 4 slices of the two skybox tables)
