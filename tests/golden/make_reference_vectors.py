@@ -479,6 +479,16 @@ def function_vectors(path, n=300, seed=9):
         q = reservoir(np.concatenate([row[:21], [1.0, 1.0]]).astype(np.float32))
         d, sp, jac = r.shift(V(dst_pos[k]), V(dst_n[k]), material(dst_mat[k]), V(src_pos[k]), V(dst_n[k]), material(dst_mat[k]), q)
         out["shift_out"][k] = d.to_list() + sp.to_list() + [jac]
+    # set_directional_light (pathtracer.py:139-144) runs in PYTHON scope: the direction is normalised in double and rounded by the store
+    # into the f32 field, the cone's cosine likewise -- what host.make_scene_params hands the library
+    ldirs = np.concatenate([rng.uniform(-3.0, 3.0, (200, 3)), [[1, 1, 1], [1, 1, -1], [0, 1, 0], [1e-3, 2, -5e2]]]).astype(np.float64)
+    cones = np.concatenate([rng.uniform(0.0, 0.5, 200), [0.1, 0.025, 0.0, 3.0]]).astype(np.float64)
+    out["light_in"], out["light_cone"] = ldirs, cones
+    out["light_dir"], out["light_cos"] = np.zeros((len(ldirs), 3), np.float32), np.zeros(len(ldirs), np.float32)
+    for k in range(len(ldirs)):
+        r.set_directional_light(tuple(float(x) for x in ldirs[k]), float(cones[k]), (1.0, 1.0, 1.0))
+        out["light_dir"][k] = r.light_direction[None].to_list()
+        out["light_cos"][k] = r.light_cone_cos_theta_max[None]
     # the skybox parameterisation (atmos.py:428-455) at the table size of the sky-lookup case
     import make_golden as mg2
     sky_case = ("s6", 0, 16, 8, 2, 0, False, [], ("given", 64, 5))

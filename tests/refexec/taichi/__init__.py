@@ -206,7 +206,7 @@ class Vector:
         i = _b.int(i)
         self._v[i] = _cast1(val, type(self._v[i]))
     def __repr__(self): return f"Vector({[x.item() if hasattr(x, 'item') else x for x in self._v]})"
-    def to_list(self): return [x.item() for x in self._v]
+    def to_list(self): return [x.item() if hasattr(x, "item") else x for x in self._v]
 
     def __getattr__(self, name):
         try:
@@ -403,7 +403,12 @@ def acos(x): return _map(lambda v: _np.float32(_elem["acos"](_f(v))), x)
 def atan2(y, x): return _map(lambda a, c: _np.float32(_elem["atan2"](_f(a), _f(c))), y, x)
 def exp(x): return _map(lambda v: _np.float32(_elem["exp"](_f(v))), x)
 def log(x): return _map(lambda v: _np.float32(_elem["log"](_f(v))), x)
-def sqrt(x): return _map(lambda v: _np.sqrt(_f(v)), x)
+def _py(v):
+    """A Python number in Python scope: Taichi's functions fall back to Python's math there (double)."""
+    return _scope[0] == 0 and isinstance(v, (_b.int, _b.float)) and not isinstance(v, _b.bool)
+
+
+def sqrt(x): return _map(lambda v: _m.sqrt(v) if _py(v) else _np.sqrt(_f(v)), x)
 def floor(x): return _map(lambda v: _np.floor(_f(v)), x)
 def ceil(x): return _map(lambda v: _np.ceil(_f(v)), x)
 def abs(x): return _map(lambda v: _b.abs(v), x)  # noqa: A001

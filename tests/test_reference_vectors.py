@@ -176,6 +176,10 @@ def test_oracle_functions_equal_reference_source():
         zero_jac += out[6] == 0.0
     assert 10 < zero_jac < len(v["shift_out"]) - 10      # both rejected and accepted shifts
     o.close()
+    for k in range(len(v["light_in"])):      # the boundary's own arithmetic: set_directional_light's Python-scope normalisation and cosine
+        sp = host.make_scene_params(light_direction=tuple(v["light_in"][k]), light_cone=float(v["light_cone"][k]))
+        assert _same(np.array(list(sp.light_direction), np.float32), v["light_dir"][k]), ("light direction", k)
+        assert _same(np.float32(sp.light_cos_theta_max), v["light_cos"][k]), ("cone cosine", k)
     o = orc.Oracle(host.make_config(16, 8, max_depth=2, sky_res=64), threads=1)     # project_sky / unproject_sky (atmos.py:428-455)
     for k in range(len(v["sky_dir"])):
         out = np.zeros(2, np.float32)

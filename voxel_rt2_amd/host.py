@@ -19,10 +19,12 @@ def make_config(width, height, *, voxel_edges=0.06, exposure=3.0, max_depth=4, u
 
 
 def normalize3(v):
-    """ti.Vector(direction).normalized() evaluated in float32 (pathtracer.py:140)."""
-    v = np.asarray(v, dtype=np.float32)
-    n = np.sqrt(np.float32(v[0] * v[0] + v[1] * v[1]) + v[2] * v[2], dtype=np.float32)
-    return (np.float32(1.0) / n) * v
+    """ti.Vector(direction).normalized() as set_directional_light evaluates it (pathtracer.py:140): in PYTHON scope, where Taichi's
+    vectors hold Python numbers and compute in double; the result is rounded to float32 once, by the store into the f32 field."""
+    v = [float(x) for x in v]
+    n = (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]) ** 0.5
+    inv = 1.0 / n
+    return np.array([inv * x for x in v], dtype=np.float32)
 
 
 def make_scene_params(*, floor_height=0.0, floor_color=(1.0, 1.0, 1.0), floor_material=1, background_color=(0.0, 0.0, 0.0),
