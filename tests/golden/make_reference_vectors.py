@@ -499,8 +499,41 @@ def function_vectors(path, n=300, seed=9):
     uv = rng.uniform(0.0, 1.0, (300, 2)).astype(np.float32)
     out["sky_uv_in"] = uv
     out["sky_dir_out"] = np.array([sky.r.atmos.unproject_sky(V(t)).to_list() for t in uv], np.float32)
+    # voxel authoring as the example scripts do it: Scene.round_idx (scene.py:131-137, restated here: the class needs a window) and the
+    # reference's Renderer.set_voxel (pathtracer.py:1325-1328, math_utils.py:86-92) -- ties and near-ties of the rounding, float material
+    # ids (example8.py:7), colours outside [0, 1] and on exact byte fractions
+    global _author_r
+    _author_r = sky.r
+    A = 1500
+    aidx = rng.uniform(-63.4, 62.4, (A, 3))
+    aidx[::5] = np.round(aidx[::5]) + rng.choice([0.5, -0.5, 0.49999997, 0.0], (len(aidx[::5]), 3))
+    aidx = np.clip(aidx, -63.4, 62.4).astype(np.float32)
+    amat = np.where(np.arange(A) % 3 != 0, rng.integers(0, 100, A).astype(np.float64), rng.uniform(0, 99, A)).astype(np.float32)
+    acol = rng.uniform(-0.1, 1.1, (A, 3))
+    acol[::7] = np.round(acol[::7] * 255) / 255
+    acol = acol.astype(np.float32)
+    for k in range(A):
+        _author(*[float(x) for x in aidx[k]], float(amat[k]), *[float(c) for c in acol[k]])
+    w = sky.r.world
+    cells = np.argwhere(w.voxel_material.a != 0)
+    out.update(author_idx=aidx, author_mat=amat, author_color=acol, author_cells=cells.astype(np.int16),
+               author_cell_mat=w.voxel_material.a[tuple(cells.T)], author_cell_rgb=w.voxel_color.a[tuple(cells.T)])
     np.savez_compressed(path, **out)
     print(os.path.basename(path), {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.shape}, flush=True)
+
+
+_author_r = None
+
+
+@taichi.func
+def _round_idx(idx_):
+    idx = taichi.cast(idx_, taichi.f32)
+    return taichi.Vector([taichi.round(idx[0]), taichi.round(idx[1]), taichi.round(idx[2])]).cast(taichi.i32)
+
+
+@taichi.kernel
+def _author(i: taichi.f32, j: taichi.f32, k: taichi.f32, mat: taichi.f32, cr: taichi.f32, cg: taichi.f32, cb: taichi.f32):
+    _author_r.set_voxel(_round_idx(taichi.Vector([i, j, k])), mat, taichi.Vector([cr, cg, cb]))
 
 
 def config_of(case):

@@ -413,7 +413,7 @@ def floor(x): return _map(lambda v: _np.floor(_f(v)), x)
 def ceil(x): return _map(lambda v: _np.ceil(_f(v)), x)
 def abs(x): return _map(lambda v: _b.abs(v), x)  # noqa: A001
 def pow(x, y): return _map(_pow, x, y)  # noqa: A001
-def round(x): return _map(lambda v: _np.float32(_m.floor(v + 0.5) if v >= 0 else _m.ceil(v - 0.5)), x)  # noqa: A001
+def round(x): return _map(lambda v: _np.float32(_m.floor(_b.float(v) + 0.5) if v >= 0 else _m.ceil(_b.float(v) - 0.5)), x)  # noqa: A001  (half away from zero, exactly: the sum in double)
 
 
 def _pick(a, c, take_a):

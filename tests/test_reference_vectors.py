@@ -190,3 +190,22 @@ def test_oracle_functions_equal_reference_source():
         L.orc_unit_unproject_sky(C.c_void_p(o._ctx), f(np.ascontiguousarray(v["sky_uv_in"][k])), f(out))
         assert _same(out, v["sky_dir_out"][k]), ("unproject_sky", k)
     o.close()
+
+
+def test_voxel_authoring_equals_reference_source():
+    """What an example script's kernel does to the grid -- Scene.set_voxel -> round_idx -> Renderer.set_voxel (scene.py:131-141,
+    pathtracer.py:1325-1328): rounding half away from zero, the i8 cast of (possibly fractional) material ids, u8(clamp(c) * 255) in
+    f32 -- through this repo's scene.py and voxel store against the reference's own set_voxel (functions.npz: 1 500 calls)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(HERE))
+    import scene as product_scene
+    from voxel_rt2_amd.renderer import VoxelStore
+    v = np.load(os.path.join(HERE, "golden", "reference", "functions.npz"))
+    vs = VoxelStore()
+    vs._init_voxels(128)
+    for idx, mat, col in zip(v["author_idx"], v["author_mat"], v["author_color"]):
+        vs.set_voxel(product_scene.Scene.round_idx(idx), float(mat), [float(c) for c in col])
+    cells = np.argwhere(vs.voxel_material != 0)
+    assert np.array_equal(cells, v["author_cells"].astype(np.int64))
+    assert np.array_equal(vs.voxel_material[tuple(cells.T)], v["author_cell_mat"])
+    assert np.array_equal(vs.voxel_color[tuple(cells.T)], v["author_cell_rgb"])
