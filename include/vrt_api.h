@@ -196,6 +196,16 @@ int vrt_reserve_cus(vrt_ctx* ctx, int n_cus);
  * camera ray walked, as the reference and the oracle do); on = 2 counts what the timed schedule does (the samples fused
  * into one launch share their camera rays, so a pixel's camera ray is walked -- and counted -- once). */
 int vrt_set_instrumented(vrt_ctx* ctx, int on);
+/* Occupancy queries OUTSIDE the grid.  The reference's walk can take one more step after its ray has left the grid
+ * (hit_distance a rounding error short of `far`, raytracer.py:104) and then calls query_occupancy with a cell coordinate of -1
+ * or grid_res; linearize_index (raytracer.py:17-38) does not check, so the bit it reads belongs to ANOTHER cell (x = 128 is
+ * x = 0 of the next row; z = 128 at LOD 0 is the start of the LOD-1 region) and a set bit is reported as a hit on a voxel
+ * outside the grid, which voxel_surface_color paints black (voxel_world.py:27-32, 46): black specks on the far faces of dense
+ * grids.  on = 0 (default): such a query reads "empty" -- the walk's documented meaning.  on = 1: it reads the bit the
+ * reference's index arithmetic addresses (bits before the array or behind its 2 * grid_res^3 read 0), so the frame equals
+ * what the reference's source computes, specks included; every ray is walked (no culling) and the launches use the
+ * instrumented kernel instantiations, which carry that code.  Takes effect at the next vrt_accumulate. */
+int vrt_set_reference_indexing(vrt_ctx* ctx, int on);
 /* Hash of the sources this library was built from (voxel_rt2_amd/build.py): ties measured counters
  * (profiles/traffic.json) to the build they were measured on. */
 const char* vrt_build_id(void);

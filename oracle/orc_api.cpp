@@ -40,6 +40,8 @@ orc_ctx* orc_create(const vrt_config* cfg, int n_threads) {
     return c;
 }
 void orc_destroy(orc_ctx* c) { delete c; }
+/* vrt_set_reference_indexing: occupancy queries outside the grid follow the reference's own index arithmetic (orc_world.h) */
+int orc_set_reference_indexing(orc_ctx* c, int on) { c->r.voxel_raytracer.reference_indexing = on != 0; return 0; }
 
 int orc_upload_voxels(orc_ctx* c, const int8_t* mat, const uint8_t* rgb) {
     size_t n = c->r.world.voxel_material.size();

@@ -5,12 +5,18 @@
  *
  * Deviations from the reference, all on undefined behaviour:
  *  - LOD bases: the reference formula (raytracer.py:32) addresses past the end of its own
- *    allocation for LOD >= 2.  The oracle keeps the meaning "bit = any solid voxel in the
- *    2^lod cube" and stores the LODs back to back (row-major z*r*r + y*r + x inside a LOD,
- *    raytracer.py:35-37).
+ *    allocation for LOD >= 2 (it needs 2n - 2n/2^lods bits, n = res^3, and allocates 8n/7).  The
+ *    oracle uses the reference's bases and row-major order inside a LOD (raytracer.py:32-37) over an
+ *    array long enough to hold what they address: 2n bits.
  *  - a query outside the grid (the DDA steps to x = 128 or -1 when a ray leaves the volume and
  *    float rounding keeps hit_distance <= far for one more iteration) reads a neighbouring bit
- *    or out of bounds in the reference; here it is EMPTY.
+ *    or out of bounds in the reference; here it is EMPTY by default.  With `reference_indexing`
+ *    (orc_set_reference_indexing; the product's vrt_set_reference_indexing) such a query reads the bit
+ *    the reference's own index arithmetic addresses -- x = res is x = 0 of the next row, z = res at
+ *    LOD 0 is the start of the LOD-1 region, ... -- and memory before or behind the 2n bits reads 0:
+ *    what the reference's source computes when executed over a zero-initialised array of that
+ *    length (tests/golden/make_reference_vectors.py), black specks on the far faces of dense grids
+ *    included.
  */
 #ifndef ORC_WORLD_H
 #define ORC_WORLD_H
@@ -30,30 +36,29 @@ struct VoxelOctreeRaytracer {
     int n_lods = 7; /* raytracer.py:9 */
     uint32_t lod_base[16];
     std::vector<uint32_t> occupancy;
+    bool reference_indexing = false; /* queries outside the grid: false = empty, true = the reference's index arithmetic */
 
     void init(int res) {
         voxel_grid_res = res;
         n_lods = 0;
         while ((1 << n_lods) < res) n_lods++;
-        uint32_t total = 0;
-        for (int i = 0; i < n_lods; i++) {
-            lod_base[i] = total;
-            uint32_t r = (uint32_t)(res >> i);
-            total += r * r * r;
-        }
-        occupancy.assign(total / 32 + 1, 0u); /* raytracer.py:10-15 */
+        const uint32_t n = (uint32_t)res * (uint32_t)res * (uint32_t)res;
+        for (int i = 0; i < n_lods; i++) lod_base[i] = i == 0 ? 0u : (n << 1) - ((n << 1) >> i); /* raytracer.py:20-32 */
+        /* raytracer.py:10-15 allocates sum(r^3) / 32 + 1 words: LODs >= 2 lie behind that (header).  2n bits hold them all */
+        occupancy.assign((size_t)(n << 1) / 32, 0u);
     }
-    /* raytracer.py:17-38 */
-    uint32_t linearize_index(I3 ipos, int lod) const {
+    /* raytracer.py:17-38 (signed, like the reference's i32 arithmetic: a coordinate may be -1) */
+    int32_t linearize_index(I3 ipos, int lod) const {
         int r = voxel_grid_res >> lod;
-        return lod_base[lod] + (uint32_t)(ipos.z * (r * r) + ipos.y * r + ipos.x);
+        return (int32_t)lod_base[lod] + (ipos.z * (r * r) + ipos.y * r + ipos.x);
     }
     /* raytracer.py:40-44 */
     bool query_occupancy(I3 ipos, int lod, Stats* st = nullptr) const {
         if (st) st->queries++;
         int r = voxel_grid_res >> lod;
-        if (ipos.x < 0 || ipos.y < 0 || ipos.z < 0 || ipos.x >= r || ipos.y >= r || ipos.z >= r) return false;
-        uint32_t idx = linearize_index(ipos, lod);
+        if (!reference_indexing && (ipos.x < 0 || ipos.y < 0 || ipos.z < 0 || ipos.x >= r || ipos.y >= r || ipos.z >= r)) return false;
+        int32_t idx = linearize_index(ipos, lod);
+        if (idx < 0 || (size_t)(idx >> 5) >= occupancy.size()) return false; /* memory nobody wrote */
         return (occupancy[idx >> 5] & (1u << (idx & 31))) != 0;
     }
     /* raytracer.py:46-70.  voxels: int8 [res][res][res] indexed [x][y][z] (offset already applied) */
@@ -64,7 +69,7 @@ struct VoxelOctreeRaytracer {
             for (int j = 0; j < n; j++)
                 for (int k = 0; k < n; k++)
                     if (voxels[((size_t)i * n + j) * n + k] > 0) {
-                        uint32_t idx = linearize_index(I3{i, j, k}, 0);
+                        int32_t idx = linearize_index(I3{i, j, k}, 0);
                         occupancy[idx >> 5] |= 1u << (idx & 31);
                     }
         for (int lod = 1; lod < n_lods; lod++) {
@@ -78,7 +83,7 @@ struct VoxelOctreeRaytracer {
                                 for (int c = 0; c < 2; c++)
                                     empty = empty && !query_occupancy(I3{i * 2 + a, j * 2 + b, k * 2 + c}, lod - 1);
                         if (!empty) {
-                            uint32_t idx = linearize_index(I3{i, j, k}, lod);
+                            int32_t idx = linearize_index(I3{i, j, k}, lod);
                             occupancy[idx >> 5] |= 1u << (idx & 31);
                         }
                     }

@@ -8,6 +8,8 @@ ALL_CASES = {
     "ref_sunlit_moving_32x16_d4": ("sunlit", 0, 32, 16, 4, 9, False, [("accumulate", 2), ("end_frame",), ("move", 0.45), ("accumulate", 1),
                                                                         ("end_frame",), ("still", 3), ("accumulate", 1)]),
     "ref_dense_32x16_d3": ("dense", 12345, 32, 16, 3, 3, False, [("accumulate", 1)]),
+    # the dense case of tests/golden (make_golden.CASES["dense_48x40_d5"]) as the reference's source computes it: five bounces, three passes
+    "ref_dense_48x40_d5": ("dense", 12345, 48, 40, 5, 3, False, [("accumulate", 3)]),
     # ReSTIR through a camera move: spatial reuse on the half-resolution pass, albedo demodulation (pathtracer.py:981-982), Catmull-Rom history
     "ref_sunlit_restir_moving_32x24_d4": ("sunlit", 0, 32, 24, 4, 17, True, [("accumulate", 2), ("end_frame",), ("move", 0.44), ("accumulate", 1),
                                                                                ("end_frame",), ("still", 3), ("accumulate", 2)]),

@@ -27,14 +27,19 @@ mg = _load("make_golden")
 CASES = _load("reference_cases").CASES
 
 
-def check(session, name):
-    """Every buffer, every pixel, bit for bit -- except the pixels a fixture lists in `undefined_px`: there one of the path's rays
-    left the grid a rounding error before the reference's own `far` test caught it, and the reference's bit index for the cell
-    outside the grid addressed another cell's SET bit (make_reference_vectors.py; only the dense grid has such pixels).  The
-    reference's value there is an artefact of undefined indexing, the build reads "empty" outside the grid."""
+def check(session, name, reference_indexing=False):
+    """Every buffer, every pixel, bit for bit.  DEFAULT mode leaves out the pixels a fixture lists in `undefined_px`: there one of
+    the path's rays left the grid a rounding error before the reference's own `far` test caught it, and the reference's bit index
+    for the cell outside the grid addressed another cell's SET bit (make_reference_vectors.py; only the dense grid has such
+    pixels) -- the build reads "empty" outside the grid.  With `reference_indexing` the session reads such a
+    cell the reference's way (vrt_set_reference_indexing, include/vrt_api.h) and NOTHING is left out."""
+    if reference_indexing:
+        session.set_reference_indexing(True)
     got = mg.run_case(session, CASES[name])
     want = np.load(os.path.join(HERE, "golden", "reference", name + ".npz"))
-    skip = want["undefined_px"] if "undefined_px" in want.files else np.zeros((got["hdr"].shape[0], got["hdr"].shape[1]), bool)
+    skip = np.zeros((got["hdr"].shape[0], got["hdr"].shape[1]), bool)
+    if "undefined_px" in want.files and not reference_indexing:
+        skip = want["undefined_px"]
     assert skip.sum() <= 0.01 * skip.size
     spread = skip.copy()    # the reflection-depth prepass averages a 4x4 box (offsets -1..2, pathtracer.py:1030-1045)
     for dy in range(-2, 2):
@@ -48,6 +53,9 @@ def check(session, name):
         if same.shape == skip.shape:
             same |= spread if key == "gbuf_refl_depth" else skip
         assert same.all(), f"{name}: {key} differs from the reference's output at {int((~same).sum())} of {same.size} pixels, first {np.argwhere(~same)[:4].tolist()}"
+
+
+DENSE = sorted(n for n in CASES if "undefined_px" in np.load(os.path.join(HERE, "golden", "reference", n + ".npz")).files)
 
 
 def test_every_case_has_a_fixture():
@@ -84,30 +92,69 @@ def test_gpu_equals_reference_source(name, schedule, monkeypatch):
     g.close()
 
 
+# ---- the reference's own reading of cells outside the grid (vrt_set_reference_indexing): no pixel is left out -------------------
+def test_dense_cases_have_pixels_the_default_mode_leaves_out():
+    assert len(DENSE) >= 2 and all(np.load(os.path.join(HERE, "golden", "reference", n + ".npz"))["undefined_px"].any() for n in DENSE)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_with_reference_indexing_equals_reference_source_everywhere(name):
+    """EVERY case, not only the dense ones: the reference's source made those reads in all of them (at coarse levels they only
+    cost it a descent), so the mode must leave the other frames as they are."""
+    o = orc.Oracle(mg.config_of(CASES[name]), threads=4)
+    check(o, name, reference_indexing=True)
+    o.close()
+
+
+@pytest.mark.parametrize("pooled", [False, True])
+@pytest.mark.parametrize("name", DENSE + ["ref_sunlit_48x24_d5"])
+def test_emulated_device_code_with_reference_indexing(name, pooled, monkeypatch):
+    if pooled:
+        monkeypatch.setenv("VRT_EMU_POOL", "1")      # the pooled schedule's stage functions (flat descent)
+    e = emu.Emulated(mg.config_of(CASES[name]))
+    check(e, name, reference_indexing=True)
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("schedule", ["pool", "fused"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gpu_with_reference_indexing_equals_reference_source_everywhere(name, schedule, monkeypatch):
+    from voxel_rt2_amd import _lib
+    from voxel_rt2_amd._session import NativeSession
+    monkeypatch.setenv("VRT_RENDER", schedule)
+    g = NativeSession(_lib.load(), "vrt_", mg.config_of(CASES[name]))
+    check(g, name, reference_indexing=True)
+    g.close()
+
+
 def test_oracle_rays_equal_reference_source():
     """600 rays through VoxelOctreeRaytracer.raytrace as the reference's raytracer.py computes them (rays_sunlit.npz): distance and
     iteration count for every ray -- NaN distances included (axis-parallel rays that start outside their slab: 0 * inf, raytracer.py:94,
     133) -- and, for hits, the voxel and the face normal.  On a miss the reference's cell / normal are whatever its last step left
     OUTSIDE the grid, where its own occupancy reads are out of bounds (undefined; the build reads "empty" there):
-    not compared, nothing downstream reads them (pathtracer.py:205)."""
+    not compared in the default mode, nothing downstream reads them (pathtracer.py:205).  With the reference's indexing
+    (orc_set_reference_indexing) they ARE compared, on every ray: the walk then ends in the reference's own last state."""
     from voxel_rt2_amd import host, scenes
     v = np.load(os.path.join(HERE, "golden", "reference", "rays_sunlit.npz"))
     mat, rgb, params = scenes.scene_sunlit(0)
-    o = orc.Oracle(host.make_config(16, 8, max_depth=2), threads=1)
-    orc.setup(o, mat, rgb, params)
     n = len(v["distance"])
-    hits = 0
-    for k in range(n):
-        got = o.raytrace(v["origin"][k], v["direction"][k], 1e-6, np.inf)
-        want = v["distance"][k]
-        assert np.float32(got["distance"]).view(np.uint32) == want.view(np.uint32) or (np.isnan(got["distance"]) and np.isnan(want)), k
-        assert got["iters"] == v["iters"][k], k
-        if np.isfinite(want):
-            hits += 1
-            assert list(got["cell"]) == list(v["cell"][k]), k
-            assert np.array_equal(got["normal"], v["normal"][k]), k
-    assert hits > 300 and np.isnan(v["distance"]).sum() > 10 and np.isinf(v["distance"]).sum() > 100
-    o.close()
+    for ref_idx in (False, True):
+        o = orc.Oracle(host.make_config(16, 8, max_depth=2), threads=1)
+        o.set_reference_indexing(ref_idx)
+        orc.setup(o, mat, rgb, params)
+        hits = 0
+        for k in range(n):
+            got = o.raytrace(v["origin"][k], v["direction"][k], 1e-6, np.inf)
+            want = v["distance"][k]
+            assert np.float32(got["distance"]).view(np.uint32) == want.view(np.uint32) or (np.isnan(got["distance"]) and np.isnan(want)), k
+            assert got["iters"] == v["iters"][k], k
+            if np.isfinite(want) or ref_idx:
+                hits += bool(np.isfinite(want))
+                assert list(got["cell"]) == list(v["cell"][k]), k
+                assert np.array_equal(got["normal"], v["normal"][k]), k
+        assert hits > 300 and np.isnan(v["distance"]).sum() > 10 and np.isinf(v["distance"]).sum() > 100
+        o.close()
 
 
 def _bits(a):

@@ -92,3 +92,4 @@ def declare(lib, prefix):
     sig("get_stats", C.c_int, P, C.POINTER(VrtStats))
     sig("last_error", C.c_char_p)
     sig("is_instrumented", C.c_int)
+    sig("set_reference_indexing", C.c_int, P, C.c_int)

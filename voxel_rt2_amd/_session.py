@@ -82,6 +82,11 @@ class NativeSession:
     def set_camera(self, cam):
         self._call("set_camera", C.byref(cam))
 
+    def set_reference_indexing(self, on=True):
+        """Occupancy queries outside the grid read the bit the reference's own index arithmetic addresses (raytracer.py:17-44)
+        instead of "empty": include/vrt_api.h, vrt_set_reference_indexing."""
+        self._call("set_reference_indexing", int(bool(on)))
+
     # -- work ------------------------------------------------------------------------------
     def prepare(self):
         self._call("prepare")

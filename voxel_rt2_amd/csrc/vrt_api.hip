@@ -44,6 +44,7 @@ struct vrt_ctx {
     bool have_scene = false, have_cam = false, prepared = false, have_prev = false;
     bool instrumented = false;
     bool count_as_timed = false;      // instrumented launches keep the camera-ray reuse of the timed schedule (vrt_set_instrumented(ctx, 2))
+    bool ref_oob = false;             // vrt_set_reference_indexing: cells outside the grid are read the reference's way (vrt_trace.h, ref_bit)
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = true;
@@ -259,7 +260,8 @@ static FrameParams make_frame_params(const vrt_ctx* c) {
 }
 // launches that count the reference's work walk every ray, as the reference and the oracle do; VRT_CULL=0 for A/B runs
 static bool culling(const vrt_ctx* c) {
-    bool cull = c->cull_active && !(c->instrumented && !c->count_as_timed);
+    // with the reference's indexing a ray clear of every solid voxel can still "hit" outside the grid: every ray is walked
+    bool cull = c->cull_active && !(c->instrumented && !c->count_as_timed) && !c->ref_oob;
     if (const char* e = getenv("VRT_CULL")) cull = cull && atoi(e) != 0;
     return cull;
 }
@@ -267,6 +269,7 @@ static SceneData make_scene_data(const vrt_ctx* c) {
     SceneData sc;
     sc.pyr.l0 = c->d_l0; sc.pyr.l1 = c->d_l1; sc.pyr.l2 = c->d_l2; sc.pyr.l3 = c->d_l3;
     sc.pyr.l0c = c->d_l0c; sc.pyr.l0c_base = c->d_l0c_base; sc.pyr.l0c_count = c->d_l0c_base + 512;
+    sc.pyr.ref_oob = c->ref_oob ? 1 : 0;
     sc.grid = c->d_grid;
     sc.mats = c->d_mats;
     sc.sky.scattering = c->d_sky_scat;
@@ -492,6 +495,14 @@ int vrt_set_instrumented(vrt_ctx* c, int on) {
     return VRT_OK;
 }
 
+int vrt_set_reference_indexing(vrt_ctx* c, int on) {
+    if (!c) return fail(VRT_E_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    c->ref_oob = on != 0;
+    c->render_blocks = 0;   // other kernel instantiations (the instrumented ones carry the code): the grid is sized again
+    return VRT_OK;
+}
+
 int vrt_prepare(vrt_ctx* c) {
     if (!c) return fail(VRT_E_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
@@ -699,7 +710,8 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
 }
 
 static int accumulate_impl(vrt_ctx* c, int n_samples) {
-    const bool restir = c->cfg.use_restir != 0, instr = c->instrumented;
+    // (the instrumented instantiations are the ones that carry the reference's out-of-grid reading: vrt_set_reference_indexing)
+    const bool restir = c->cfg.use_restir != 0, instr = c->instrumented || c->ref_oob;
     if (c->render_blocks == 0) {
         // Two schedules of the same per-path code: the fused one (a lane owns a path, vrt_path.h) and the pooled one
         // (a wave owns a pool of paths in LDS and works stage by stage, vrt_pool.h).  The pooled kernel packs pixel

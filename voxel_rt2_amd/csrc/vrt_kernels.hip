@@ -134,11 +134,16 @@ __global__ void k_build_l0c(const unsigned long long* __restrict__ l0, const uns
 }
 
 // ---- render ----------------------------------------------------------------------------------
-template <int G_>
+// OOB: the instantiation can read cells outside the grid the reference's way (oob_capable_of, vrt_trace.h).  It is the INSTRUMENTED
+// instantiations that can (a context with vrt_set_reference_indexing launches those): the timed kernels carry no test for it.
+template <int G_, bool OOB_ = false>
 struct LdsPyramid {  // coarse levels in LDS, fine level through L2
     static constexpr int G = G_;
     static constexpr bool flat_descend = false;  // its kernels walk with few active lanes: descend()'s early outs win
     static constexpr bool cull = true;
+    static constexpr bool oob_capable = OOB_;
+    bool oob;   // wave-uniform: Pyramid::ref_oob
+    __device__ __forceinline__ bool oob_ref() const { return oob; }
     const unsigned long long* l0;
     const unsigned long long* l1;
     const unsigned long long* l2;
@@ -153,10 +158,13 @@ struct LdsPyramid {  // coarse levels in LDS, fine level through L2
 // hundred words, and the fine word is the load every other DDA step depends on (L2: ~700 cycles, LDS: ~130).
 // CULL: rays that cannot hit a voxel are not walked (cull_ray, vrt_trace.h).  A launch over a scene whose solids fill the grid
 // has nothing to cull and runs the instantiation without the test (its registers cost a dense 4K frame 2.5 %).
-template <int G_, bool CULL_, bool SHBR_ = false>
+template <int G_, bool CULL_, bool SHBR_ = false, bool OOB_ = false>
 struct LdsPyramid2 {
     static constexpr int G = G_;
     static constexpr bool cull = CULL_;
+    static constexpr bool oob_capable = OOB_;
+    bool oob;
+    __device__ __forceinline__ bool oob_ref() const { return oob; }
     static constexpr bool flat_descend = true;   // the pooled kernel walks with nearly full waves
     static constexpr bool shadow_branchy = SHBR_;   // ... except SHADE's inline shadow rays in a dense grid (raytrace, vrt_trace.h)
     const unsigned long long* l0;
@@ -182,10 +190,13 @@ struct LdsPyramid2 {
 // they miss LDS by a factor of 13) through L1 / L2 with the current brick's word cached in registers per ray.  A
 // workgroup is eight waves (one per CU: eight 13.5 KB path pools + 32.5 KB of pyramid + the material table = 148 KB of
 // the CU's 160 KB), so the level is staged once per CU.
-template <bool CULL_, bool SHBR_>
-struct LdsPyramid2<256, CULL_, SHBR_> {
+template <bool CULL_, bool SHBR_, bool OOB_>
+struct LdsPyramid2<256, CULL_, SHBR_, OOB_> {
     static constexpr int G = 256;
     static constexpr bool cull = CULL_;
+    static constexpr bool oob_capable = OOB_;
+    bool oob;
+    __device__ __forceinline__ bool oob_ref() const { return oob; }
     static constexpr bool flat_descend = true;
     static constexpr bool shadow_branchy = SHBR_;
     const unsigned long long* l0;
@@ -231,9 +242,10 @@ __global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_re
     if (blockIdx.x == 0 && threadIdx.x < VRT_WORK_HEADS) next_counter[threadIdx.x * VRT_WORK_HEAD_STRIDE] = 0u;  // the next launch's heads (idle during this launch)
     if (blockIdx.x == 0 && threadIdx.x == 0) next_counter[1] = 0u;  // and its "drain announced" word
     __syncthreads();
-    LdsPyramid<G> P;
+    LdsPyramid<G, INSTR> P;
     P.l0 = sc.pyr.l0; P.l1 = s_l1; P.l2 = s_l2;
     P.w3 = (G == 256) ? sc.pyr.l3[0] : 0ULL;
+    P.oob = sc.pyr.ref_oob != 0;
     SceneData scl = sc;
     scl.mats = s_mats;
     scl.cull = s_cull;
@@ -345,8 +357,9 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
     __shared__ uint32_t s_pool[WAVES][PF_COUNT * VRT_POOL_SLOTS];
     __shared__ uint32_t s_state[WAVES][VRT_POOL_WORDS * 64];
     __shared__ uint32_t s_list[WAVES][VRT_POOL_SLOTS];
-    LdsPyramid2<G, CULL, SHBR> P;
+    LdsPyramid2<G, CULL, SHBR, INSTR> P;
     P.l0 = sc.pyr.l0; P.l2 = s_l2;
+    P.oob = sc.pyr.ref_oob != 0;
     if constexpr (BIG) {
         for (int i = threadIdx.x; i < 4096; i += blockDim.x) s_l1[i] = sc.pyr.l1[i];
         if (threadIdx.x < 64) s_l2[threadIdx.x] = sc.pyr.l2[threadIdx.x];
@@ -649,9 +662,10 @@ __global__ __launch_bounds__(256, (PHASE == 1 ? VRT_GRIS_MIN_WAVES_A : PHASE == 
     for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) s_mats_x[i] = gb.mats_x[i];
     __shared__ float s_cull[8];
     if (threadIdx.x < 8) s_cull[threadIdx.x] = sc.cull[threadIdx.x];
-    LdsPyramid<G> P;
+    LdsPyramid<G, INSTR> P;
     P.l0 = sc.pyr.l0; P.l1 = s_l1; P.l2 = s_l2;
     P.w3 = (G == 256) ? sc.pyr.l3[0] : 0ULL;
+    P.oob = sc.pyr.ref_oob != 0;
     SceneData scl = sc;
     scl.mats = s_mats;
     scl.cull = s_cull;

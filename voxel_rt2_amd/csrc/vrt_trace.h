@@ -46,6 +46,70 @@ VRT_DEV int texel_index(int x, int y, int z) {
     return (((((z >> 2) << 6) | (y >> 2)) << 6 | (x >> 2)) << 6) | brick_bit(x, y, z);
 }
 
+// ---- queries outside the grid, read the reference's way (vrt_set_reference_indexing) --------------------------------------
+// The reference's walk can take one more step after its ray has left the grid (hit_distance a rounding error short of `far`,
+// raytracer.py:104) and then queries a cell with a coordinate of -1 or G.  linearize_index (raytracer.py:17-38) does not
+// check: bit index = base(lod) + z r^2 + y r + x with r = G >> lod and base(lod) = 2n - (2n >> lod), n = G^3 -- so x = r
+// is x = 0 of the next row, z = r at LOD 0 the start of the LOD-1 region, and so on; ANOTHER cell's bit, or the unused gap
+// behind a level (LOD l holds n / 8^l bits of the n / 2^l its base reserves).  By default such a query reads "empty" here
+// (DESIGN.md section 5).  A pyramid type that is `oob_capable` and whose oob_ref() is true follows the reference instead:
+// ref_bit() finds the level and cell a bit index belongs to and reads THAT cell's occupancy from the bit bricks; bits
+// before the array or behind its 2n read 0 (memory nobody wrote).  Cold code: only cells outside the grid come here, and
+// only instrumented kernel instantiations compile it in (the timed ones keep "empty").
+template <class T, class = void> struct oob_capable_of { static constexpr bool value = false; };
+template <class T> struct oob_capable_of<T, std::void_t<decltype(T::oob_capable)>> { static constexpr bool value = T::oob_capable; };
+
+// occupancy of cell (cx, cy, cz) of LOD l (inside the grid), from the brick words: what descend() tests level by level
+template <class PyrT>
+VRT_DEV bool cell_occupied(const PyrT& P, int l, int cx, int cy, int cz) {
+    constexpr int G = PyrT::G;
+    typedef GridDim<G> D;
+    const int x = cx << l, y = cy << l, z = cz << l;   // a LOD-0 cell inside it
+    if (l >= 6) {
+        if (G == 256) {
+            const unsigned long long w3 = P.load_l3();
+            return l == 7 ? (w3 & brick_sub(x >> 6, y >> 6, z >> 6)) != 0ULL : ((w3 >> brick_bit(x >> 6, y >> 6, z >> 6)) & 1ULL) != 0ULL;
+        }
+        return P.load_l2((((z >> 6) << D::s2) | (y >> 6)) << D::s2 | (x >> 6)) != 0ULL;
+    }
+    if (l >= 4) {
+        const unsigned long long w2 = P.load_l2((((z >> 6) << D::s2) | (y >> 6)) << D::s2 | (x >> 6));
+        return l == 5 ? (w2 & brick_sub(x >> 4, y >> 4, z >> 4)) != 0ULL : ((w2 >> brick_bit(x >> 4, y >> 4, z >> 4)) & 1ULL) != 0ULL;
+    }
+    if (l >= 2) {
+        const unsigned long long w1 = P.load_l1((((z >> 4) << D::s1) | (y >> 4)) << D::s1 | (x >> 4));
+        return l == 3 ? (w1 & brick_sub(x >> 2, y >> 2, z >> 2)) != 0ULL : ((w1 >> brick_bit(x >> 2, y >> 2, z >> 2)) & 1ULL) != 0ULL;
+    }
+    const unsigned long long w0 = P.load_l0((((z >> 2) << D::s0) | (y >> 2)) << D::s0 | (x >> 2));
+    return l == 1 ? (w0 & brick_sub(x, y, z)) != 0ULL : ((w0 >> brick_bit(x, y, z)) & 1ULL) != 0ULL;
+}
+// bit `idx` of the reference's occupancy array (raytracer.py:40-44 over the layout of :17-38)
+template <class PyrT>
+VRT_DEV bool ref_bit(const PyrT& P, int idx) {
+    constexpr int G = PyrT::G, LG = (G == 256) ? 8 : 7, n2 = 2 * G * G * G;
+    if (idx < 0) return false;
+    int l = 0;
+    for (int k = 1; k < GridDim<G>::lods; k++) if (idx >= n2 - (n2 >> k)) l = k;
+    const int off = idx - (l ? n2 - (n2 >> l) : 0), rb = LG - l;
+    if (off >= (1 << (3 * rb))) return false;   // the gap behind LOD l, or past the last level
+    return cell_occupied(P, l, off & ((1 << rb) - 1), (off >> rb) & ((1 << rb) - 1), off >> (2 * rb));
+}
+// the reference's inner loop (raytracer.py:110-118) for a LOD-0 cell (x, y, z) with a coordinate outside the grid
+template <class PyrT>
+VRT_DEV int descend_outside(const PyrT& P, int x, int y, int z, int lod, bool& solid, int& nq) {
+    constexpr int G = PyrT::G, LG = (G == 256) ? 8 : 7, n2 = 2 * G * G * G;
+    nq = 0;
+    bool sample;
+    for (;;) {
+        const int r = 1 << (LG - lod);
+        sample = ref_bit(P, (lod ? n2 - (n2 >> lod) : 0) + (z >> lod) * (r * r) + (y >> lod) * r + (x >> lod));
+        nq += 1;
+        if (sample && lod > 0) lod -= 1; else break;
+    }
+    solid = sample;
+    return lod;
+}
+
 // Level the reference's descent ends at when it starts at `lod` on LOD-0 cell (x,y,z), and whether
 // it ended on a solid voxel.  `nq` receives the number of query_occupancy calls the reference
 // would have made (for the algorithmic-bytes counters).
@@ -55,7 +119,10 @@ VRT_DEV int descend(const PyrT& P, int x, int y, int z, int lod, bool& solid, Br
     typedef GridDim<G> D;
     solid = false;
     nq = 1;
-    if ((x | y | z) & ~(G - 1)) return lod;  // outside the grid: empty (UB in the reference)
+    if ((x | y | z) & ~(G - 1)) {  // outside the grid: empty (undefined in the reference) ...
+        if constexpr (oob_capable_of<PyrT>::value) { if (P.oob_ref()) return descend_outside(P, x, y, z, lod, solid, nq); }  // ... or the reference's own reading
+        return lod;
+    }
     const int start = lod;
     if (G == 256 && lod == 7) {  // the 2x2x2 block of 64^3 cells around the cell, from the top word
         if ((P.load_l3() & brick_sub(x >> 6, y >> 6, z >> 6)) == 0ULL) return 7;
@@ -122,6 +189,7 @@ VRT_DEV int descend_flat(const PyrT& P, const CoarseWords& c, int x, int y, int 
     constexpr int G = PyrT::G;
     typedef GridDim<G> D;
     const bool inside = ((x | y | z) & ~(G - 1)) == 0;  // outside the grid: empty, as in descend()
+    if constexpr (oob_capable_of<PyrT>::value) { if (!inside && P.oob_ref()) return descend_outside(P, x, y, z, lod, solid, nq); }
     const int xm = x & (G - 1), ym = y & (G - 1), zm = z & (G - 1);
     unsigned occ = (c.w2 != 0ULL ? 64u : 0u) | (brick_two_lods(c.w2, xm >> 4, ym >> 4, zm >> 4) << 4) |
                    (brick_two_lods(c.w1, xm >> 2, ym >> 2, zm >> 2) << 2);
@@ -153,7 +221,9 @@ struct GlobalPyramid {  // all brick levels read from global memory
     static constexpr int G = G_;
     static constexpr bool flat_descend = false;
     static constexpr bool cull = true;   // rays that cannot hit a voxel are not walked (cull_ray); false compiles the test out
+    static constexpr bool oob_capable = true;
     Pyramid p;
+    VRT_DEV bool oob_ref() const { return p.ref_oob != 0; }
     VRT_DEV unsigned long long load_l0(int i) const { return p.l0[i]; }
     VRT_DEV unsigned long long load_l1(int i) const { return p.l1[i]; }
     VRT_DEV unsigned long long load_l2(int i) const { return p.l2[i]; }

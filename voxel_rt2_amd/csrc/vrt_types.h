@@ -148,6 +148,7 @@ struct Pyramid {
     const unsigned long long* l0c;
     const uint32_t* l0c_base;   // [512]
     const uint32_t* l0c_count;  // [1]: non-empty l0 words
+    int ref_oob;                // queries outside the grid follow the reference's index arithmetic (vrt_set_reference_indexing; ref_bit, vrt_trace.h)
 };
 
 struct SkyTables {
