@@ -14,7 +14,8 @@ tile with no data-path communication, and every step's HDR tiles are gathered to
 (inside the timed region).
 
 Rank 0 prints ONE JSON line: the headline throughput, the roofline of its dominant kernel
-(k_render_pool), the CPU-oracle baseline timed on this box's host cores and a `secondary` list:
+(k_render_pool), the CPU-oracle baseline timed on this box's host cores, a `secondary` list and, as the
+LAST key, a compact `summary` of every workload's value (a record that keeps only the end of the line keeps these):
 on one GPU the other BASELINE configs in their one-GPU form (config 3: sky + clouds + ReSTIR at
 1080p; config 4: dense 128^3 at 3840x2160; config 5: dense 256^3 at 3840x2160), each with its own
 dominant kernel, duration, algorithmic bytes and roofline fraction, plus the reference's own loop
@@ -262,10 +263,10 @@ class ShardedRun:
         # Row tiles: start from an equal split, then (untimed) let every rank measure its tile's device time and move the
         # tile boundaries so that all ranks carry the same cost -- the sky rows of S1 cost a fraction of the floor rows.
         self.bounds = split_rows(H, world)
-        self.sess = make_session(self.bounds[rank])
         if balance and world > 1:
             user_overlap = os.environ.get("VRT_OVERLAP")
-            os.environ["VRT_OVERLAP"] = "0"  # isolated launches while measuring
+            os.environ["VRT_OVERLAP"] = "0"  # isolated launches while measuring (the library reads it when a context is created)
+            self.sess = make_session(self.bounds[rank])
             for _ in range(2):
                 self.sess.accumulate(spp)
                 lib.vrt_reset_stats(C.c_void_p(self.sess._ctx))
@@ -277,10 +278,12 @@ class ShardedRun:
                 self.bounds = parallel.rebalance_rows(self.bounds, [float(t.item()) for t in allc], H)
                 self.sess.close()
                 self.sess = make_session(self.bounds[rank])
+            self.sess.close()
             if user_overlap is None:
                 os.environ.pop("VRT_OVERLAP", None)
             else:
                 os.environ["VRT_OVERLAP"] = user_overlap
+        self.sess = make_session(self.bounds[rank])
         self.steps_done = 0
         self.tiles_gathered = 0
         if world > 1:
@@ -538,6 +541,15 @@ def main():
     if rank == 0:
         out["secondary"] = sec
         out["cpu_baseline"] = cpu_baseline(mat, rgb, params) if (not args.no_cpu_baseline and world == 1) else None
+        # every workload's number once more, compactly, as the LAST key: a record that keeps only the end of this (long) line keeps these
+        by_name = {s_.get("name", ""): s_ for s_ in (sec or [])}
+        pick = lambda prefix: next((v.get("value", v.get("error")) for k, v in by_name.items() if k.startswith(prefix)), None)  # noqa: E731
+        rl = out["roofline"]
+        out["summary"] = {"unit": "Mpath-samples/s", "n_gpus": world, "config2": out["value"], "config3": pick("config3"), "config4": pick("config4"),
+                          "config5": pick("config5"), "scene_api_default": pick("scene_api_default"),
+                          "roofline_frac": rl["frac"], "roofline_frac_all_launches_in_flight": (rl.get("all_launches_in_flight") or {}).get("frac"),
+                          "config3_roofline_frac": ((by_name.get("config3_s6_sky_clouds_restir_1080p") or {}).get("roofline") or {}).get("frac"),
+                          "cpu_baseline": (out["cpu_baseline"] or {}).get("value")}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -64,8 +64,8 @@ class Scene:
         self.image = None
 
     @staticmethod
-    def round_idx(idx_):  # scene.py:131-137
-        return [int(ti.round(float(idx_[0]))), int(ti.round(float(idx_[1]))), int(ti.round(float(idx_[2])))]
+    def round_idx(idx_):  # scene.py:131-137: ti.cast(idx_, ti.f32), ti.round, cast to i32
+        return [x if x.__class__ is int else int(ti.round(float(x))) for x in (idx_[0], idx_[1], idx_[2])]
 
     def set_voxel(self, idx, mat, color):
         self.renderer.set_voxel(self.round_idx(idx), mat, color)

@@ -64,7 +64,9 @@ def _div0(a, b):
 def _kadd(a, b):
     ta, tb = a.__class__, b.__class__
     if ta is float:
-        if tb is float: return _f32(a + b)
+        if tb is float:
+            try: return _up(_pk(a + b))[0]
+            except OverflowError: return _f32(a + b)
         if tb is int or tb is bool: return _f32(a + _i2f(b))
     elif ta is int or ta is bool:
         if tb is float: return _f32(_i2f(a) + b)
@@ -75,7 +77,9 @@ def _kadd(a, b):
 def _ksub(a, b):
     ta, tb = a.__class__, b.__class__
     if ta is float:
-        if tb is float: return _f32(a - b)
+        if tb is float:
+            try: return _up(_pk(a - b))[0]
+            except OverflowError: return _f32(a - b)
         if tb is int or tb is bool: return _f32(a - _i2f(b))
     elif ta is int or ta is bool:
         if tb is float: return _f32(_i2f(a) - b)
@@ -86,7 +90,9 @@ def _ksub(a, b):
 def _kmul(a, b):
     ta, tb = a.__class__, b.__class__
     if ta is float:
-        if tb is float: return _f32(a * b)
+        if tb is float:
+            try: return _up(_pk(a * b))[0]
+            except OverflowError: return _f32(a * b)
         if tb is int or tb is bool: return _f32(a * _i2f(b))
     elif ta is int or ta is bool:
         if tb is float: return _f32(_i2f(a) * b)
@@ -98,12 +104,14 @@ def _kdiv(a, b):
     """`/`: true division in default_fp, whatever the operands."""
     ta, tb = a.__class__, b.__class__
     if (ta is float or ta is int or ta is bool) and (tb is float or tb is int or tb is bool):
-        if ta is not float: a = _i2f(a)
-        if tb is not float: b = _i2f(b)
+        if ta is not float: a = _b.float(a) if -16777216 <= a <= 16777216 else _f32(a)      # i32 -> f32
+        if tb is not float: b = _b.float(b) if -16777216 <= b <= 16777216 else _f32(b)
         try:
-            return _f32(a / b)
+            return _up(_pk(a / b))[0]
         except ZeroDivisionError:
             return _div0(a, b)
+        except OverflowError:
+            return _f32(a / b)
     return a / b
 
 
@@ -192,7 +200,7 @@ def _map(fn, *args):
 
 
 def _num(x):
-    """A number entering a vector: f32 / i32 in kernel scope, as it is in Python scope."""
+    """A number entering a vector through the general constructor: f32 / i32 in kernel scope, as it is in Python scope."""
     if _scope[0] and x.__class__ is float:
         return _f32(x)
     return x
@@ -259,60 +267,27 @@ class Vector:
         object.__setattr__(v, "_v", vals)
         return v
 
-    # arithmetic: Python's in Python scope, f32 / i32 in kernel scope
-    def _bin(self, o, kfn, pfn, rev=False):
-        fn = kfn if _scope[0] else pfn
-        a = self._v
-        if o.__class__ is Vector:
-            c = o._v
-        elif isinstance(o, (list, tuple)):
-            c = o
-        else:
-            return Vector._new([fn(o, x) for x in a] if rev else [fn(x, o) for x in a])
-        if len(c) != len(a):
-            raise ValueError(f"vector sizes differ: {len(a)} and {len(c)}")
-        return Vector._new([fn(y, x) for x, y in zip(a, c)] if rev else [fn(x, y) for x, y in zip(a, c)])
-
-    def __add__(self, o): return self._bin(o, _kadd, lambda a, c: a + c)
-    def __radd__(self, o): return self._bin(o, _kadd, lambda a, c: a + c, True)
-    def __sub__(self, o): return self._bin(o, _ksub, lambda a, c: a - c)
-    def __rsub__(self, o): return self._bin(o, _ksub, lambda a, c: a - c, True)
-    def __mul__(self, o): return self._bin(o, _kmul, lambda a, c: a * c)
-    def __rmul__(self, o): return self._bin(o, _kmul, lambda a, c: a * c, True)
-    def __truediv__(self, o): return self._bin(o, _kdiv, lambda a, c: a / c)
-    def __rtruediv__(self, o): return self._bin(o, _kdiv, lambda a, c: a / c, True)
-    def __floordiv__(self, o): return self._bin(o, _kfloordiv, lambda a, c: a // c)
-    def __rfloordiv__(self, o): return self._bin(o, _kfloordiv, lambda a, c: a // c, True)
-    def __mod__(self, o): return self._bin(o, _kmod, lambda a, c: a % c)
-    def __rmod__(self, o): return self._bin(o, _kmod, lambda a, c: a % c, True)
-    def __pow__(self, o): return self._bin(o, _kpow, lambda a, c: a ** c)
-    def __rpow__(self, o): return self._bin(o, _kpow, lambda a, c: a ** c, True)
-    def __and__(self, o): return self._bin(o, _kand, lambda a, c: _b.int(a) & _b.int(c))
-    def __or__(self, o): return self._bin(o, _kor, lambda a, c: _b.int(a) | _b.int(c))
-    def __xor__(self, o): return self._bin(o, _kxor, lambda a, c: _b.int(a) ^ _b.int(c))
-    __rand__, __ror__, __rxor__ = __and__, __or__, __xor__
-    def __lshift__(self, o): return self._bin(o, _klshift, lambda a, c: a << c)
-    def __rshift__(self, o): return self._bin(o, _krshift, lambda a, c: a >> c)
-    def __neg__(self): return Vector._new([-a for a in self._v])
-    def __pos__(self): return self
-    def __abs__(self): return Vector._new([_b.abs(a) for a in self._v])
-    # comparisons give 0/1 vectors like Taichi
-    def __eq__(self, o): return self._bin(o, lambda a, c: _b.int(a == c), lambda a, c: _b.int(a == c))
-    def __ne__(self, o): return self._bin(o, lambda a, c: _b.int(a != c), lambda a, c: _b.int(a != c))
-    def __lt__(self, o): return self._bin(o, lambda a, c: _b.int(a < c), lambda a, c: _b.int(a < c))
-    def __le__(self, o): return self._bin(o, lambda a, c: _b.int(a <= c), lambda a, c: _b.int(a <= c))
-    def __gt__(self, o): return self._bin(o, lambda a, c: _b.int(a > c), lambda a, c: _b.int(a > c))
-    def __ge__(self, o): return self._bin(o, lambda a, c: _b.int(a >= c), lambda a, c: _b.int(a >= c))
-
+    # arithmetic: Python's in Python scope, f32 / i32 in kernel scope (methods are attached below: _vec_op)
     # methods the examples call
     def dot(self, o):
         if not _scope[0]:
             return _b.sum(a * c for a, c in zip(self._v, o))
+        a = self._v
+        if o.__class__ is Vector and len(a) == 3:
+            c = o._v
+            a0, a1, a2 = a
+            c0, c1, c2 = c
+            if (a0.__class__ is float and a1.__class__ is float and a2.__class__ is float and
+                    c0.__class__ is float and c1.__class__ is float and c2.__class__ is float):
+                try:      # ((a0 c0 + a1 c1) + a2 c2), every product and sum rounded to binary32
+                    return _up(_pk(_up(_pk(_up(_pk(a0 * c0))[0] + _up(_pk(a1 * c1))[0]))[0] + _up(_pk(a2 * c2))[0]))[0]
+                except OverflowError:
+                    pass
         acc = None
         for a, c in zip(self._v, o):      # left to right
             p = _kmul(a, c)
             acc = p if acc is None else _kadd(acc, p)
-        return acc
+        return acc if acc is not None else 0
 
     def sum(self):
         if not _scope[0]:
@@ -345,6 +320,62 @@ class Vector:
     def all(self): return _b.all(_b.bool(x) for x in self._v)
 
 
+def _vec_op(kfn, pfn, rev=False):
+    """A binary operator method of Vector: `kfn` element-wise in kernel scope, `pfn` in Python scope; scalars broadcast."""
+    new = Vector._new
+    if rev:
+        def method(self, o):
+            fn = kfn if _scope[0] else pfn
+            a = self._v
+            if o.__class__ is Vector:
+                c = o._v
+            elif o.__class__ is list or o.__class__ is tuple:
+                c = o
+            else:
+                return new([fn(o, x) for x in a])
+            if len(c) != len(a):
+                raise ValueError(f"vector sizes differ: {len(a)} and {len(c)}")
+            return new([fn(y, x) for x, y in zip(a, c)])
+    else:
+        def method(self, o):
+            fn = kfn if _scope[0] else pfn
+            a = self._v
+            if o.__class__ is Vector:
+                c = o._v
+            elif o.__class__ is list or o.__class__ is tuple:
+                c = o
+            else:
+                return new([fn(x, o) for x in a])
+            if len(c) != len(a):
+                raise ValueError(f"vector sizes differ: {len(a)} and {len(c)}")
+            return new([fn(x, y) for x, y in zip(a, c)])
+    return method
+
+
+def _attach():
+    import operator as _o
+    V = Vector
+    for name, kfn, pfn in (("add", _kadd, _o.add), ("sub", _ksub, _o.sub), ("mul", _kmul, _o.mul), ("truediv", _kdiv, _o.truediv),
+                           ("floordiv", _kfloordiv, _o.floordiv), ("mod", _kmod, _o.mod), ("pow", _kpow, _o.pow)):
+        setattr(V, f"__{name}__", _vec_op(kfn, pfn))
+        setattr(V, f"__r{name}__", _vec_op(kfn, pfn, True))
+    for name, kfn, pfn in (("and", _kand, lambda a, c: _b.int(a) & _b.int(c)), ("or", _kor, lambda a, c: _b.int(a) | _b.int(c)),
+                           ("xor", _kxor, lambda a, c: _b.int(a) ^ _b.int(c))):
+        setattr(V, f"__{name}__", _vec_op(kfn, pfn))
+        setattr(V, f"__r{name}__", _vec_op(kfn, pfn))
+    V.__lshift__, V.__rshift__ = _vec_op(_klshift, _o.lshift), _vec_op(_krshift, _o.rshift)
+    # comparisons give 0/1 vectors like Taichi
+    for name, fn in (("eq", lambda a, c: _b.int(a == c)), ("ne", lambda a, c: _b.int(a != c)), ("lt", lambda a, c: _b.int(a < c)),
+                     ("le", lambda a, c: _b.int(a <= c)), ("gt", lambda a, c: _b.int(a > c)), ("ge", lambda a, c: _b.int(a >= c))):
+        setattr(V, f"__{name}__", _vec_op(fn, fn))
+    V.__neg__ = lambda self: V._new([-a for a in self._v])
+    V.__pos__ = lambda self: self
+    V.__abs__ = lambda self: V._new([_b.abs(a) for a in self._v])
+
+
+_attach()
+
+
 def _like(old, new):
     """`new` converted to the type `old` has (a typed variable or vector element being stored into)."""
     co, cn = old.__class__, new.__class__
@@ -357,12 +388,32 @@ def _like(old, new):
     return new
 
 
+_SCALARS = (float, int, bool)
+
+
 def _ctor(n, dt):
+    new = Vector._new
+
     def make(*args):
-        if len(args) == n and not _b.any(isinstance(a, (Vector, list, tuple)) for a in args):
-            if dt is float:
-                return Vector._new([_num(a) if a.__class__ is float else _num(_b.float(a)) for a in args])
-            return Vector._new([_trunc(a) if a.__class__ is float else _b.int(a) for a in args])
+        if n == 3 and len(args) == 3 and dt is float and _scope[0]:
+            a, c, d = args
+            if a.__class__ is float and c.__class__ is float and d.__class__ is float:
+                return new([a, c, d])
+        if len(args) == n:
+            v = []
+            for a in args:
+                c = a.__class__
+                if c is float:
+                    v.append(a if dt is float else _trunc(a))
+                elif c is int or c is bool:
+                    v.append(_i2f(a) if dt is float else _b.int(a))
+                else:
+                    v = None
+                    break
+            if v is not None:
+                if dt is float and not _scope[0]:
+                    return new([_b.float(a) for a in args])      # Python scope: doubles
+                return new(v)
         flat = []
         for a in args:
             if isinstance(a, (Vector, list, tuple)):

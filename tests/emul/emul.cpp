@@ -163,7 +163,7 @@ int emu_upload_voxels(Emu* c, const int8_t* mat, const uint8_t* rgb) {
 }
 static void derive_materials(Emu* c) {
     c->mats_x.assign(128 * 8, 0.0f);
-    for (int id = 0; id < 128; id++) store_mat_derived(c->mats_x.data(), id, mat_derive(load_material(c->mats.data(), id)));
+    for (int id = 0; id < 128; id++) { const Material m = load_material(c->mats.data(), id); store_mat_derived(c->mats_x.data(), id, mat_derive(m), material_unit_range(m)); }
 }
 int emu_upload_materials(Emu* c, const float* t) { memcpy(c->mats.data(), t, 128 * 14 * 4); derive_materials(c); return 0; }
 int emu_upload_cloud_texture(Emu*, const uint8_t*) { return 0; }

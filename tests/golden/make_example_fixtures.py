@@ -61,7 +61,21 @@ def describe(r):
         use_physical_sky=int(r.use_physical_atmosphere[None]), use_clouds=int(r.atmos.use_clouds[None]))
 
 
-if __name__ == "__main__":
+def record_to(name, outdir):
+    """One script, for tests/test_examples_shim.py (which runs the eleven scripts as parallel processes): the authored arrays and
+    what describe() says about them, into outdir/<script>.npz / .json."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        r = record(name, tmp)
+        d = describe(r)
+        d["calls"] = list(r.calls)
+        np.savez(os.path.join(outdir, name + ".npz"), voxel_material=r.voxel_material, voxel_color=r.voxel_color)
+        json.dump(d, open(os.path.join(outdir, name + ".json"), "w"))
+
+
+if __name__ == "__main__" and len(sys.argv) == 4 and sys.argv[1] == "--record":
+    record_to(sys.argv[2], sys.argv[3])
+elif __name__ == "__main__":
     import tempfile
     out = {}
     with tempfile.TemporaryDirectory() as tmp:

@@ -417,7 +417,13 @@ def round(x): return _map(lambda v: _np.float32(_m.floor(_b.float(v) + 0.5) if v
 
 
 def _pick(a, c, take_a):
+    """The chosen operand of ti.max / ti.min, IN THE OPERANDS' COMMON TYPE: they are binary operations with Taichi's promotion
+    (ti.max(x, 0) with an f32 x is an f32 zero -- a variable first assigned from it is an f32 variable)."""
     r = a if take_a else c
+    if isinstance(a, (_b.int, _b.float, _np.generic)) and isinstance(c, (_b.int, _b.float, _np.generic)):
+        t = _promote(_b.int(a) if isinstance(a, _b.bool) else a, _b.int(c) if isinstance(c, _b.bool) else c)
+        if t is not None:
+            return _conv(r, _np.float32 if t is _np.float64 else _np.int32 if t is _np.int64 else t)
     return _typed(r) if isinstance(r, (_b.int, _b.float)) else r
 
 
@@ -958,7 +964,8 @@ def _param_info(fn):
 
 _KERNEL_BUILTINS = {"abs": abs, "max": max, "min": min, "pow": pow, "round": round, "int": lambda x=0: _cast1(x, _np.int32),
                     "float": lambda x=0.0: _cast1(x, _np.float32), "all": lambda x: x.all() if isinstance(x, Vector) else _b.all(x),
-                    "any": lambda x: x.any() if isinstance(x, Vector) else _b.any(x)}
+                    "any": lambda x: x.any() if isinstance(x, Vector) else _b.any(x),
+                    "range": lambda *a: _krange(*a)}
 
 
 def _compile(fn, fdef, byref):
@@ -1047,8 +1054,34 @@ def kernel(fn): return _dsl(fn)
 def data_oriented(cls): return cls
 
 
+class _Range:
+    """The index set of a kernel-scope `for`: range(...) or ti.ndrange(...).  A loop over it is a RUNTIME loop whose indices are i32
+    values (`i * 0.1` is an f32 product) -- unless it is wrapped in ti.static(...), which unrolls it over Python integers, i.e.
+    compile-time constants (`i * 0.1` is folded in double and rounded once where it meets a typed value)."""
+    def __init__(self, ranges): self.ranges = ranges
+
+    def python(self):
+        return self.ranges[0] if len(self.ranges) == 1 else _it.product(*self.ranges)
+
+    def __iter__(self):
+        if _scope[0] == 0:
+            return iter(self.python())
+        if len(self.ranges) == 1:
+            return (_np.int32(a) for a in self.ranges[0])
+        return (tuple(_np.int32(a) for a in idx) for idx in _it.product(*self.ranges))
+
+    def __len__(self): return _b.int(_np.prod([len(r) for r in self.ranges]))
+
+
+def _krange(*a):
+    """`range` inside a kernel or func."""
+    return _Range([range(*[_b.int(x) for x in a])])
+
+
 def static(x, *rest):
-    return x if not rest else (x,) + rest
+    if rest:
+        return (static(x),) + tuple(static(r) for r in rest)
+    return x.python() if isinstance(x, _Range) else x
 
 
 def ndrange(*dims):
@@ -1056,7 +1089,7 @@ def ndrange(*dims):
     for d in dims:
         lo, hi = (d[0], d[1]) if isinstance(d, (tuple, list, Vector)) else (0, d)
         rs.append(range(_b.int(lo), _b.int(hi)))
-    return rs[0] if len(rs) == 1 else _it.product(*rs)
+    return _Range(rs)
 
 
 def grouped(it):
@@ -1064,7 +1097,7 @@ def grouped(it):
         for idx in it._indices():
             yield Vector(list(idx))
         return
-    for idx in _parallel(it):
+    for idx in _parallel(it.python() if isinstance(it, _Range) else it):
         yield Vector(list(idx) if isinstance(idx, tuple) else [idx])
 
 

@@ -390,8 +390,8 @@ def test_fused_samples_equal_separate_launches(monkeypatch):
     assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
     for which in (_abi.BUF_GBUF_DEPTH, _abi.BUF_GBUF_NORMAL, _abi.BUF_GBUF_REFL_DEPTH, _abi.BUF_HISTORY_DIFFUSE, _abi.BUF_HISTORY_SPECULAR):
         assert np.array_equal(fused.fetch_buffer(which).view(np.uint8), o.fetch_buffer(which).view(np.uint8)), which
-    monkeypatch.setenv("VRT_FUSE", "1")
-    nofuse = gpu_session(cfg)
+    monkeypatch.setenv("VRT_FUSE", "1")      # a development switch: the build that reads it
+    nofuse = NativeSession(_lib.load_dev(), "vrt_", cfg)
     orc.setup(nofuse, mat, rgb, params)
     nofuse.accumulate(7)
     assert np.array_equal(nofuse.fetch_hdr().view(np.uint32), a.view(np.uint32))

@@ -20,10 +20,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W, H, DEPTH = 640, 360, 6
 
 
-def render(calls=(4, 4, 4, 3, 4), reserve=None):
+def render(calls=(4, 4, 4, 3, 4), reserve=None, dev=False):
+    """dev: through build_variants/libvrt_dev.so, the build that reads the development switches (VRT_STREAMS, VRT_DRAIN_GATE,
+    VRT_TEST_FAIL_LAUNCH, ...: csrc/vrt_api.hip read_knobs) -- the shipped library ignores them."""
     mat, rgb, params = scenes.scene_sunlit(0)
     cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=DEPTH, seed=5)
-    s = NativeSession(_lib.load(), "vrt_", cfg)
+    s = NativeSession(_lib.load_dev() if dev else _lib.load(), "vrt_", cfg)
     if reserve is not None:
         s.reserve_cus(reserve)
     orc.setup(s, mat, rgb, params)
@@ -55,6 +57,8 @@ def test_overlapped_launches_with_gate(reference_frame, monkeypatch):
 def test_gate_left_out(reference_frame, monkeypatch):
     monkeypatch.setenv("VRT_DRAIN_GATE", "0")
     hdr, st = render()
+    assert st["pipeline_flags"] & 3 == 3, "the shipped library does not read development switches"
+    hdr, st = render(dev=True)
     assert st["pipeline_flags"] & 3 == 1
     assert np.array_equal(hdr.view(np.uint32), reference_frame.view(np.uint32))
 
@@ -89,13 +93,13 @@ def test_pipeline_depths_over_many_launches(monkeypatch):
     for streams, div in (("4", "2"), ("2", "1"), ("4", "3"), ("8", "4"), ("8", "2")):
         monkeypatch.setenv("VRT_STREAMS", streams)
         monkeypatch.setenv("VRT_GRID_DIV", div)
-        hdr, st = render(calls)
+        hdr, st = render(calls, dev=True)
         assert st["pipeline_flags"] & 1 == 1
         assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32)), (streams, div)
     monkeypatch.delenv("VRT_STREAMS")
     monkeypatch.delenv("VRT_GRID_DIV")
     monkeypatch.setenv("VRT_DEEP_ITEMS", "0")   # the policy's other side: this frame is "large"
-    hdr, _ = render(calls)
+    hdr, _ = render(calls, dev=True)
     assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32))
 
 
@@ -108,7 +112,7 @@ def test_restir_samples_fused_in_the_render_launch(monkeypatch):
     cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=DEPTH, seed=9, use_restir=True)
 
     def run():
-        s = NativeSession(_lib.load(), "vrt_", cfg)
+        s = NativeSession(_lib.load_dev(), "vrt_", cfg)     # (VRT_FUSE_RESTIR is a development switch)
         orc.setup(s, mat, rgb, params)
         for n in (4, 3):
             s.accumulate(n)
@@ -166,7 +170,7 @@ def test_camera_ray_records_under_contention():
 def test_accumulate_failure_rolls_back(monkeypatch):
     """A launch that fails to queue (injected: VRT_TEST_FAIL_LAUNCH) returns an error, leaves nobody waiting at the dispatch
     gate, and the context renders on afterwards -- with the result of a context that never saw the failure."""
-    lib = _lib.load()
+    lib = _lib.load_dev()     # the fault-injection hook is compiled into the development build only
     mat, rgb, params = scenes.scene_sunlit(0)
     cfg = host.make_config(320, 200, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=4, seed=2)
     good = NativeSession(lib, "vrt_", cfg)

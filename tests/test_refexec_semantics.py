@@ -123,6 +123,39 @@ def test_python_scope_vectors_hold_python_numbers():
     assert f(np.float32(3.0)) == np.float32(np.float32(OZONE[0]) * np.float32(3.0))
 
 
+def test_loop_indices_are_i32_values_unless_the_loop_is_static():
+    """`for i in range(n)` in a kernel is a runtime loop: i is an i32 VALUE and `i * 0.1` an f32 product; under ti.static(...) the loop
+    is unrolled over Python integers and `i * 0.1` folds in double (reference example6.py:60-64: vec3(0.5 - i * 0.1))."""
+    @ti.func
+    def f():
+        out = []
+        for i in range(3, 4):
+            out.append(0.5 - i * 0.1)
+        for i in ti.static(range(3, 4)):
+            out.append(ti.Vector([0.5 - i * 0.1])[0])
+        for i, j in ti.ndrange((3, 4), 1):
+            out.append(0.5 - i * 0.1)
+        return out
+    runtime, static, nd = f()
+    want = np.float32(np.float32(0.5) - np.float32(np.float32(3) * np.float32(0.1)))
+    assert runtime.dtype == np.float32 and runtime == want and nd == want
+    assert static == np.float32(0.5 - 3 * 0.1) and static != want
+
+
+def test_max_and_min_promote_like_any_binary_operation():
+    """ti.max(x, 0) with an f32 x is an f32 -- also when the integer wins: a variable first assigned from it is an f32 variable
+    (reference example6.py:47-49: prob = ti.max(..., 0); prob = prob * prob)."""
+    @ti.func
+    def f(x: ti.f32):
+        p = ti.max(x, 0)
+        p = 0.25        # would truncate to 0 if p had been typed i32
+        return p, ti.min(x, 7), ti.max(2, 3)
+    p, m, k = f(np.float32(-1.5))
+    assert p.dtype == np.float32 and p == np.float32(0.25)
+    assert m.dtype == np.float32 and m == np.float32(-1.5)
+    assert k == 3
+
+
 def test_unorm8_texture_and_out_of_bounds_policies():
     t = ti.Texture(ti.Format.rgba8, (2, 2, 2))
     t.store(ti.Vector([1, 0, 1]), ti.Vector([0.5, 10 / 255.0, 1.2, 2 / 255.0]))

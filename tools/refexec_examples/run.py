@@ -1,8 +1,11 @@
-"""Cross-check of this repo's DSL shim (taichi/, scene.py: what runs the reference's example scripts in the product) against an independent
-reading of Taichi: the same script, read from /root/reference, executed under tests/refexec with the reference's own Renderer.set_voxel
-behind a stand-in Scene (scene.py here), fed the product shim's random stream; the authored voxel arrays are compared with the hashes
-of tests/golden/examples.json.      python tools/refexec_examples/run.py example4.py      (build container only; minutes per script)"""
-import sys, os, hashlib, json, runpy, time
+"""Cross-check of this repo's DSL shim (taichi/, scene.py: what runs the reference's example scripts in the product) against an
+independent reading of Taichi: the same script, read from /root/reference, executed under tests/refexec with the reference's own Scene and
+Renderer.set_voxel (scene.py here subclasses the reference's class), fed what Taichi leaves undefined exactly as the product shim defines
+it -- ti.random(): the shim's stream under ti.seed(0); sin / cos / ...: libm's double routines rounded once to binary32 (taichi/math.py) --
+and the authored voxel arrays are compared with the hashes of tests/golden/examples.json.
+
+    python tools/refexec_examples/run.py example4.py      (build container only; minutes per script)"""
+import sys, os, hashlib, json, math, runpy, time
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path[:0] = [HERE, os.path.join(ROOT, "tests", "refexec"), "/root/reference"]
@@ -17,6 +20,15 @@ def rnd(index):
     w = (w >> 22) ^ w
     return (w >> 8) * (1.0 / 16777216.0)
 ti.set_random_source(rnd)
+def once(f):     # a double routine of libm on f32 arguments, its result rounded once
+    def g(*a):
+        try:
+            return np.float32(f(*[float(x) for x in a]))
+        except (ValueError, OverflowError, ZeroDivisionError):
+            return np.float32(np.nan)
+    return g
+ti.set_elementary(sin=once(math.sin), cos=once(math.cos), tan=once(math.tan), asin=once(math.asin), acos=once(math.acos),
+                  atan2=once(math.atan2), exp=once(math.exp), log=once(math.log), pow=once(math.pow))
 ti.set_out_of_bounds_reads("zero")
 import scene
 name = sys.argv[1]

@@ -1,37 +1,31 @@
-"""Harness stand-in for the reference's scene.py (which opens a window): the voxel-authoring surface the example scripts use, bound to the
-reference's own Renderer executed under tests/refexec."""
+"""Harness module the example scripts import as `scene` under tools/refexec_examples/run.py: the REFERENCE'S OWN `Scene` class
+(/root/reference/scene.py, imported from where it lies: round_idx, set_voxel, get_voxel and the setters are its code, executed under
+tests/refexec) with the two methods that need a window replaced -- the constructor (reference scene.py:113-129 without the GGUI window and
+camera) and finish() (the render loop)."""
+import importlib.util
+import sys
+import types
+
 import taichi as ti
-import numpy as np
-import renderer.pathtracer as pt
+
+# scene.py:23 reaches into Taichi for a window-system handle it only uses in the interactive loop
+for name in ("taichi.lang", "taichi.lang.impl"):
+    sys.modules.setdefault(name, types.ModuleType(name))
+sys.modules["taichi.lang.impl"]._ti_core = None
+_spec = importlib.util.spec_from_file_location("reference_scene", "/root/reference/scene.py")
+reference_scene = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(reference_scene)
 
 INSTANCES = []
 
 
-@ti.data_oriented
-class Scene:
+class Scene(reference_scene.Scene):
     def __init__(self, voxel_edges=0.06, exposure=3):
-        self.renderer = pt.Renderer(dx=1 / 64, image_res=(16, 8), up=(0, 1, 0), voxel_edges=voxel_edges, exposure=exposure)
+        self.renderer = reference_scene.Renderer(dx=reference_scene.VOXEL_DX, image_res=(16, 8), up=reference_scene.UP_DIR,
+                                                 voxel_edges=voxel_edges, exposure=exposure)
+        self.renderer.set_directional_light((1, 1, 1), 0.1, (0.0, 0.0, 0.0))   # scene.py:127
         self.args = dict(voxel_edges=voxel_edges, exposure=exposure)
         INSTANCES.append(self)
 
-    @staticmethod
-    @ti.func
-    def round_idx(idx_):          # scene.py:131-137
-        idx = ti.cast(idx_, ti.f32)
-        return ti.Vector([ti.round(idx[0]), ti.round(idx[1]), ti.round(idx[2])]).cast(ti.i32)
-
-    @ti.func
-    def set_voxel(self, idx, mat, color):      # scene.py:139-141
-        self.renderer.set_voxel(self.round_idx(idx), mat, color)
-
-    @ti.func
-    def get_voxel(self, idx):                  # scene.py:143-146
-        mat, color = self.renderer.get_voxel(self.round_idx(idx))
-        return mat, color
-
-    def set_floor(self, height, color, material=1): pass
-    def set_directional_light(self, direction, direction_noise, color): pass
-    def set_background_color(self, color): pass
-    def set_use_physical_sky(self, use): pass
-    def set_use_clouds(self, use): pass
-    def finish(self): pass
+    def finish(self):
+        pass

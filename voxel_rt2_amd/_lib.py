@@ -63,21 +63,43 @@ def _want_hw_queues(n=16):
                       RuntimeWarning, stacklevel=3)
 
 
+DEV_SO_PATH = os.path.join(os.path.dirname(_HERE), "build_variants", "libvrt_dev.so")
+_dev = None
+
+
+def load_dev():
+    """The same library built with -DVRT_DEV_KNOBS (build_variants/libvrt_dev.so): it also reads the development switches --
+    the fault-injection hook and the A/B switches (csrc/vrt_api.hip, read_knobs) -- which the shipped library does not carry.
+    For tests/test_gpu_pipeline.py and the A/B runs of tools/; built here when missing or older than the sources."""
+    global _dev
+    if _dev is None:
+        from . import build
+        if not os.path.exists(DEV_SO_PATH) or any(os.path.getmtime(p) > os.path.getmtime(DEV_SO_PATH) for p in build._deps()):
+            build.build(force=True, extra_flags=["-DVRT_DEV_KNOBS"], out=DEV_SO_PATH)
+        _dev = _open(DEV_SO_PATH)
+    return _dev
+
+
 def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    _want_hw_queues()
     if not os.path.exists(SO_PATH):
         if not build_if_missing:
             raise LibraryMissing(f"{SO_PATH} not found; run `python -m voxel_rt2_amd.build` (needs hipcc)")
         from . import build
         build.build()
+    _lib = _open(SO_PATH)
+    return _lib
+
+
+def _open(path):
+    _want_hw_queues()
     _share_hip_runtime_with_torch()
     try:
-        lib = C.CDLL(SO_PATH)
+        lib = C.CDLL(path)
     except OSError as e:
-        raise LibraryMissing(f"cannot load {SO_PATH}: {e}. The renderer only runs through the HIP library "
+        raise LibraryMissing(f"cannot load {path}: {e}. The renderer only runs through the HIP library "
                              "(ROCm runtime + an MI355X / gfx950 device); there is no CPU fallback.") from e
     _abi.declare(lib, "vrt_")
     lib.vrt_create.restype = C.c_void_p
@@ -92,7 +114,6 @@ def load(build_if_missing=True):
     lib.vrt_reset_stats.argtypes = [C.c_void_p]
     lib.vrt_detmath_probe.restype = C.c_int
     lib.vrt_detmath_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-    _lib = lib
     return lib
 
 

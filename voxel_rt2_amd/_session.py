@@ -42,9 +42,17 @@ class NativeSession:
             raise NativeError(f"{self._p}{name} failed ({rc}): {self._err()}")
 
     def close(self):
+        """Ends the session.  Page-locked arrays from host_alloc() die with it (see there): outstanding asynchronous fetches are
+        waited for first, so that no copy is still writing into memory that is being freed."""
         if self._ctx:
-            for ptr, _ in getattr(self, "_pinned", []):
-                getattr(self._lib, self._p + "host_free")(C.c_void_p(self._ctx), C.c_void_p(ptr))
+            pinned = getattr(self, "_pinned", [])
+            if pinned:
+                wait = getattr(self._lib, self._p + "fetch_wait", None)
+                if wait is not None:
+                    for slot in range(4):       # VRT_FETCH_SLOTS; a slot without a fetch returns at once
+                        wait(C.c_void_p(self._ctx), slot)
+                for ptr, _ in pinned:
+                    getattr(self._lib, self._p + "host_free")(C.c_void_p(self._ctx), C.c_void_p(ptr))
             self._pinned = []
             getattr(self._lib, self._p + "destroy")(C.c_void_p(self._ctx))
             self._ctx = None
@@ -144,7 +152,9 @@ class NativeSession:
 
     # -- presenting every frame (the reference's accumulate / fetch_image / copy_prev_matrices loop, scene.py:255-262) ---
     def host_alloc(self, shape, dtype=np.float32):
-        """Page-locked host array (vrt_host_alloc): the target of the asynchronous fetches.  Freed with the session."""
+        """Page-locked host array (vrt_host_alloc): the target of the asynchronous fetches.  The memory belongs to the SESSION:
+        close() frees it, after which the array must not be touched -- copy what has to outlive the session
+        (Renderer.present_wait returns copies)."""
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         ptr = C.c_void_p()
         self._call("host_alloc", C.c_uint64(n), C.byref(ptr))

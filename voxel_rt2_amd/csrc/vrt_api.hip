@@ -37,8 +37,54 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 struct EventPair { hipEvent_t a, b; int kind; };  // kind 0 render, 1 temporal, 2 gris
 
+// Environment switches, read ONCE when a context is created (never on the launch path).
+// The shipped library knows four: VRT_RENDER=pool|fused (which of the two schedules of the same per-path code renders),
+// VRT_OVERLAP=0 (isolated launches: what the --pmc passes and the tile balancing of bench.py measure on),
+// VRT_GATE_WATCHDOG_MS (how long a synchronisation waits at a gated launch before the host releases the gate) and the HIP
+// runtime's own GPU_MAX_HW_QUEUES (how deep a pipeline the runtime's queues carry).
+// A build with -DVRT_DEV_KNOBS (build_variants/libvrt_dev.so: `python -m voxel_rt2_amd.build --variant dev -DVRT_DEV_KNOBS`,
+// loaded by tests/test_gpu_pipeline.py and the A/B runs of tools/) adds the development switches: the fault-injection hook
+// VRT_TEST_FAIL_LAUNCH and the A/B switches VRT_CULL, VRT_DENSE, VRT_DEEP_ITEMS, VRT_DEEPER_ITEMS, VRT_STREAMS, VRT_GRID_DIV,
+// VRT_DRAIN_GATE, VRT_FUSE, VRT_FUSE_RESTIR, VRT_OVERLAP_SINGLE, VRT_FULL_BELOW, VRT_CHUNK.
+struct Knobs {
+    int render = -1;               // -1: the library's choice, 0: fused, 1: pool; -2: a value VRT_RENDER does not know
+    bool overlap = true;
+    double gate_watchdog_s = 2.0;
+    int hw_queues = 4;
+    // development switches: the defaults below are what the shipped library always runs with
+    int cull = -1, dense = -1;     // -1: decided from the scene (vrt_prepare)
+    long long deep_items = (long long)12 << 20, deeper_items = (long long)5 << 19;
+    int streams = 0, grid_div = 0; // 0: decided from the frame size (ensure_overlap)
+    bool drain_gate = true, fuse_restir = true, overlap_single = true;
+    int max_fused = VRT_MAX_FUSED, full_below = 2, chunk = 0, fail_launch = -1;
+};
+static Knobs read_knobs() {
+    Knobs k;
+    if (const char* e = getenv("VRT_RENDER")) k.render = strcmp(e, "fused") == 0 ? 0 : strcmp(e, "pool") == 0 ? 1 : -2;
+    if (const char* e = getenv("VRT_OVERLAP")) k.overlap = atoi(e) != 0;
+    if (const char* e = getenv("VRT_GATE_WATCHDOG_MS")) { const double v = atof(e); if (v > 0.0) k.gate_watchdog_s = v * 1e-3; }
+    if (const char* e = getenv("GPU_MAX_HW_QUEUES")) k.hw_queues = atoi(e);
+#if defined(VRT_DEV_KNOBS)
+    if (const char* e = getenv("VRT_TEST_FAIL_LAUNCH")) k.fail_launch = atoi(e);
+    if (const char* e = getenv("VRT_CULL")) k.cull = atoi(e) != 0;
+    if (const char* e = getenv("VRT_DENSE")) k.dense = atoi(e) != 0;
+    if (const char* e = getenv("VRT_DEEP_ITEMS")) k.deep_items = atoll(e);
+    if (const char* e = getenv("VRT_DEEPER_ITEMS")) k.deeper_items = atoll(e);
+    if (const char* e = getenv("VRT_STREAMS")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) k.streams = v; }
+    if (const char* e = getenv("VRT_GRID_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 4) k.grid_div = v; }
+    if (const char* e = getenv("VRT_DRAIN_GATE")) k.drain_gate = atoi(e) != 0;
+    if (const char* e = getenv("VRT_FUSE")) { const int v = atoi(e); if (v >= 1 && v <= VRT_MAX_FUSED) k.max_fused = v; }
+    if (const char* e = getenv("VRT_FUSE_RESTIR")) k.fuse_restir = atoi(e) != 0;
+    if (const char* e = getenv("VRT_OVERLAP_SINGLE")) k.overlap_single = atoi(e) != 0;
+    if (const char* e = getenv("VRT_FULL_BELOW")) { const int v = atoi(e); if (v >= 1 && v <= 3) k.full_below = v; }
+    if (const char* e = getenv("VRT_CHUNK")) { const int v = atoi(e); if (v >= 64 && v <= 4096) k.chunk = v / 64 * 64; }
+#endif
+    return k;
+}
+
 struct vrt_ctx {
     vrt_config cfg;
+    Knobs knobs;                      // environment switches as they stood when the context was created
     vrt_scene_params scene;
     vrt_camera cam;
     bool have_scene = false, have_cam = false, prepared = false, have_prev = false;
@@ -131,11 +177,12 @@ struct vrt_ctx {
     // HDR tiles handed over device to device (vrt_set_hdr_targets): pass k also writes its HDR rows to ring[k % n]
     std::vector<void*> hdr_targets;
     unsigned long long hdr_targets_written = 0;
+    unsigned long long hdr_targets_committed = 0;   // ... by calls that returned VRT_OK (abort_pipeline rolls back to it)
     // asynchronous fetches (vrt_fetch_*_async)
     hipStream_t fetch_stream = nullptr;
     hipEvent_t ev_fetch[VRT_FETCH_SLOTS] = {}, ev_fetch_src = nullptr, ev_cbuf_read[2] = {};
     bool fetch_valid[VRT_FETCH_SLOTS] = {}, cbuf_read_pending[2] = {};
-    int test_fail_launch = -1;           // VRT_TEST_FAIL_LAUNCH, read once at vrt_create (tests/test_gpu_pipeline.py)
+    unsigned last_full_seq = 0;          // launch_seq + 1 of the most recent launch that took every workgroup slot (0: none)
     int hist_in = 0;  // history ping-pong
     mat4 prev_view{}, prev_proj{};
     uint32_t frame = 0;
@@ -171,8 +218,7 @@ static void release_gate(vrt_ctx* c) {
 // the host (harmless when the launches are merely long; the way out when a dispatch never comes).
 static hipError_t sync_guarded(vrt_ctx* c, hipStream_t st) {
     if (c->drain_signal && c->drain_signalled) {
-        double limit = 2.0;
-        if (const char* e = getenv("VRT_GATE_WATCHDOG_MS")) { const double v = atof(e); if (v > 0.0) limit = v * 1e-3; }
+        const double limit = c->knobs.gate_watchdog_s;
         const double t0 = now_s();
         for (;;) {
             const hipError_t q = hipStreamQuery(st);
@@ -262,7 +308,7 @@ static FrameParams make_frame_params(const vrt_ctx* c) {
 static bool culling(const vrt_ctx* c) {
     // with the reference's indexing a ray clear of every solid voxel can still "hit" outside the grid: every ray is walked
     bool cull = c->cull_active && !(c->instrumented && !c->count_as_timed) && !c->ref_oob;
-    if (const char* e = getenv("VRT_CULL")) cull = cull && atoi(e) != 0;
+    if (c->knobs.cull == 0) cull = false;
     return cull;
 }
 static SceneData make_scene_data(const vrt_ctx* c) {
@@ -330,6 +376,7 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
     }
     vrt_ctx* c = new vrt_ctx();
     c->cfg = *cfg;
+    c->knobs = read_knobs();
     c->device = cfg->device;
     c->n_cu = prop.multiProcessorCount;
     c->own0 = own0; c->own1 = own1;
@@ -381,7 +428,6 @@ vrt_ctx* vrt_create(const vrt_config* cfg) {
         launch_mat_derived(c->stream, c->d_mats, c->d_mats_x);
     }
     c->last_gb_normal = c->d_gb_normal[VRT_GB_ROT - 1]; c->last_gb_depth = c->d_gb_depth[VRT_GB_ROT - 1];
-    if (const char* e = getenv("VRT_TEST_FAIL_LAUNCH")) c->test_fail_launch = atoi(e);   // fault injection for tests/test_gpu_pipeline.py, read once
     memset(&c->scene, 0, sizeof(c->scene));
     c->scene.floor_color[0] = c->scene.floor_color[1] = c->scene.floor_color[2] = 1.0f;  // pathtracer.py:91-93
     c->scene.floor_material = 1;
@@ -517,7 +563,7 @@ int vrt_prepare(vrt_ctx* c) {
         c->cull_active = box[6] != 0.0f;
         // at least half of the 4x4x4 bricks hold a voxel: a dense grid (shadow rays end after a step or two: launch_render_pool)
         c->dense_grid = box[7] >= 0.5f;
-        if (const char* e = getenv("VRT_DENSE")) c->dense_grid = atoi(e) != 0;   // A/B
+        if (c->knobs.dense >= 0) c->dense_grid = c->knobs.dense != 0;   // A/B
     }
     if (c->scene.use_physical_sky == 1) {
         SkyPrecompute sp = make_sky(c);
@@ -587,8 +633,8 @@ int vrt_sky_compute_slice(vrt_ctx* c, int slice_idx, int max_slices) {
     f3 sd, sc_;
     float cm;
     sun_of(c, sd, sc_, cm);
-    if (c->cfg.sky_res % max_slices != 0) return fail(VRT_E_INVALID, "sky_res is not a multiple of max_slices (atmos.py:162 drops the remainder: 3840 / 32 has none)");
-    int w = c->cfg.sky_res / max_slices;  // atmos.py:162
+    int w = c->cfg.sky_res / max_slices;  // atmos.py:162: floor division -- trailing columns (3840 / 32 has none) belong to no slice, as in the reference
+    if (w == 0) return VRT_OK;   // fewer columns than slices: every slice is empty
     c->main_dirty = true;
     HIP_TRY(launch_sky_slice(c->stream, make_sky(c), sd, sc_, cm, w * slice_idx, w * (slice_idx + 1)));
     return VRT_OK;
@@ -614,23 +660,20 @@ static bool ensure_overlap(vrt_ctx* c, int g) {   // g: samples of the launch th
     // run) +24 %; thirds and quarters of the slots are worse again; a 4K frame (33 M items a launch) loses 0-7 % and keeps
     // the two-deep pipeline.
     // VRT_DEEP_ITEMS: largest launch (pixels x fused samples) that gets the deep pipeline; VRT_STREAMS / VRT_GRID_DIV override.
-    size_t deep_items = (size_t)12 << 20;
-    if (const char* e = getenv("VRT_DEEP_ITEMS")) deep_items = (size_t)atoll(e);
+    const size_t deep_items = (size_t)c->knobs.deep_items;      // 12 M
     const size_t items = (size_t)c->cfg.width * (size_t)(c->own1 - c->own0) * (size_t)g;
     const bool deep = items <= deep_items;
     // Deeper still for the smallest frames -- one rank's rows of an 8-GPU split of 1080p are 1 M items a launch: eight launches
     // of a quarter of the slots each (profiles/r02_pipeline_depth.txt: +7.5 % on those rows, +1 % on half a frame, nothing on a
     // whole one).  Each render stream wants a hardware queue of its own (two streams on one queue serialise), so only where
     // the runtime was started with sixteen (GPU_MAX_HW_QUEUES, which voxel_rt2_amd/_lib.py sets unless the user has).
-    size_t deeper_items = (size_t)5 << 19;   // 2.5 M
-    if (const char* e = getenv("VRT_DEEPER_ITEMS")) deeper_items = (size_t)atoll(e);
-    int hw_queues = 4;
-    if (const char* e = getenv("GPU_MAX_HW_QUEUES")) hw_queues = atoi(e);
+    const size_t deeper_items = (size_t)c->knobs.deeper_items;   // 2.5 M
+    const int hw_queues = c->knobs.hw_queues;
     const bool deeper = deep && items <= deeper_items && hw_queues >= 16;
     c->n_streams = deeper ? 8 : deep ? 4 : 2;
     c->grid_div = deeper ? 4 : deep ? 2 : 1;
-    if (const char* e = getenv("VRT_STREAMS")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) c->n_streams = v; }
-    if (const char* e = getenv("VRT_GRID_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 4) c->grid_div = v; }
+    if (c->knobs.streams) c->n_streams = c->knobs.streams;
+    if (c->knobs.grid_div) c->grid_div = c->knobs.grid_div;
     const int n_sets = c->n_streams + 1;
     bool ok = true;
     for (int s = 0; s < n_sets - 1 && ok; s++)
@@ -646,7 +689,7 @@ static bool ensure_overlap(vrt_ctx* c, int g) {   // g: samples of the launch th
     ok = ok && hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) == hipSuccess;
     int can_wait = 0;
     bool want_gate = ok;
-    if (const char* e = getenv("VRT_DRAIN_GATE")) want_gate = want_gate && atoi(e) != 0;   // 0: launches overlap all the same, only queue earlier
+    want_gate = want_gate && c->knobs.drain_gate;   // off: launches overlap all the same, only queue earlier
     c->drain_signal = nullptr;
     if (want_gate && hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, c->device) == hipSuccess && can_wait &&
         hipExtMallocWithFlags((void**)&c->drain_signal, 8, hipMallocSignalMemory) == hipSuccess) {
@@ -673,6 +716,9 @@ static void abort_pipeline(vrt_ctx* c) {
     c->drain_signalled = false;
     for (int s = 0; s < VRT_MAX_STREAMS; s++) if (c->rstream[s]) (void)hipStreamSynchronize(c->rstream[s]);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->fetch_stream) (void)hipStreamSynchronize(c->fetch_stream);   // asynchronous fetches queued before the failure have completed
+    c->cbuf_read_pending[0] = c->cbuf_read_pending[1] = false;
+    c->hdr_targets_written = c->hdr_targets_committed;   // a tile handed out for a pass that was never queued is handed out again
     (void)hipGetLastError();
     resolve_events(c);
     // the work heads rotate with the launch number and each launch zeroes the set eight launches ahead: a launch that did not
@@ -706,6 +752,7 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
     HIP_TRY(hipSetDevice(c->device));
     const int rc = accumulate_impl(c, n_samples);
     if (rc != VRT_OK) abort_pipeline(c);
+    else c->hdr_targets_committed = c->hdr_targets_written;
     return rc;
 }
 
@@ -719,10 +766,8 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         // k_render_pool_restir keeps the reconnection state in the per-slot scratch line).  VRT_RENDER=fused selects the
         // fused kernel everywhere (A/B measurements, tests).
         bool pooled = c->cfg.width <= 4096 && c->cfg.height <= 4096 && c->cfg.max_depth <= 15;
-        if (const char* e = getenv("VRT_RENDER")) {
-            if (strcmp(e, "fused") == 0) pooled = false;
-            else if (strcmp(e, "pool") != 0) return fail(VRT_E_INVALID, "VRT_RENDER must be 'fused' or 'pool'");
-        }
+        if (c->knobs.render == -2) return fail(VRT_E_INVALID, "VRT_RENDER must be 'fused' or 'pool'");
+        if (c->knobs.render == 0) pooled = false;
         int per_cu = 0;
         if (pooled) HIP_TRY(query_render_pool_residency(c->cfg.grid_res, restir, instr, &per_cu));
         else HIP_TRY(query_render_residency(c->cfg.grid_res, restir, instr, &per_cu));
@@ -748,13 +793,11 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
     // off they only differ in their random streams, so up to VRT_MAX_FUSED of them go through ONE k_render launch
     // (work items = pixels x samples: 4x the parallelism per launch, one tail instead of four) into consecutive
     // colour planes, and ONE k_temporal launch advances the running means sample by sample in registers.
-    int max_fused = VRT_MAX_FUSED;
-    if (const char* e = getenv("VRT_FUSE")) { int v = atoi(e); if (v >= 1 && v <= VRT_MAX_FUSED) max_fused = v; }
+    const int max_fused = c->knobs.max_fused;
     // With ReSTIR on the samples fuse in the RENDER launch all the same (one reservoir plane per sample beside the colour
     // planes; the pooled kernel only): spatial reuse and accumulation then run sample by sample over the planes, as the
     // reference runs them -- the reuse pass of a sample reads nothing an earlier sample's pass wrote.  VRT_FUSE_RESTIR=0: off.
-    bool fuse_restir = c->pooled;
-    if (const char* e = getenv("VRT_FUSE_RESTIR")) { if (atoi(e) == 0) fuse_restir = false; }
+    const bool fuse_restir = c->pooled && c->knobs.fuse_restir;
     const bool can_fuse = (!restir || fuse_restir) && c->cam.camera_is_moving == 0 && c->cam.render_scale == 1.0f;
     // A persistent render launch ends in a tail: the last paths of every wave bounce on at low occupancy (about 0.16 ms
     // of a 1.5 ms launch at 1080p).  Fused launches of the pooled kernel are therefore OVERLAPPED: launch k+1 goes to
@@ -762,14 +805,13 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
     // and its temporal pass (main stream, waits for launch k only) runs.  With n_streams + 1 copies launch k+n_streams+1
     // reuses launch k's and waits for temporal pass k, so render launches follow each other without a gap and the temporal
     // passes run beside them (ensure_overlap: how deep).  Results are unchanged; VRT_OVERLAP=0 turns it off.
-    bool may_overlap = c->pooled && can_fuse && !restir;
-    if (const char* e = getenv("VRT_OVERLAP")) { if (atoi(e) == 0) may_overlap = false; }
+    const bool may_overlap = c->pooled && can_fuse && !restir && c->knobs.overlap;
     for (int done = 0; done < n_samples;) {
         int g = (can_fuse && n_samples - done > 1) ? (n_samples - done < max_fused ? n_samples - done : max_fused) : 1;
         // One-sample launches are pipelined like fused ones (the reference's own loop is one sample per call: scene.py:177,
         // 255-256): they render into plane 0 of the rotating copies instead of the HDR buffer.  VRT_OVERLAP_SINGLE=0: only fused ones.
         bool want_overlap = may_overlap;
-        if (g == 1) { if (const char* e = getenv("VRT_OVERLAP_SINGLE")) { if (atoi(e) == 0) want_overlap = false; } }
+        if (g == 1 && !c->knobs.overlap_single) want_overlap = false;
         if ((g > 1 || want_overlap) && !c->d_multi_d) {
             if (dalloc(&c->d_multi_d, c->npix * VRT_MAX_FUSED) != hipSuccess) { (void)hipGetLastError(); c->d_multi_d = nullptr; g = 1; want_overlap = false; }  // no memory: one launch per sample
         }
@@ -790,9 +832,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             for (unsigned back = 1; back <= 3u && back <= c->pipe_seq; back++)
                 if (hipEventQuery(c->ev_r[(c->pipe_seq - back) % n_sets]) == hipErrorNotReady) running++;
             (void)hipGetLastError();   // (hipErrorNotReady is the expected answer)
-            int full_below = 2;   // VRT_FULL_BELOW=n: every slot while fewer than n launches are still running (A/B)
-            if (const char* e = getenv("VRT_FULL_BELOW")) { const int v = atoi(e); if (v >= 1 && v <= 3) full_below = v; }
-            lone = running < full_below;
+            lone = running < c->knobs.full_below;   // every slot while fewer than two launches are still running
         }
         if (overlapped) {
             if (c->main_dirty) {  // uploads / prepare / sky kernels queued on the main stream come first
@@ -804,9 +844,12 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             // dispatch when the launch whose workgroup slots this one will take starts to drain: the one before it, or with
             // launches of half the slots the one before that (the signal carries the number + 1 of the latest launch draining)
             // -- unless the one before it took EVERY slot (a lone launch): then that one has to drain first
+            // and never for a launch OLDER than the last one that took every slot: until that one drains there is no slot at all
             const unsigned back = c->prev_launch_full ? 1u : (unsigned)c->grid_div;
-            if (c->drain_signal && c->drain_signalled && c->launch_seq + 1u > back)
-                HIP_TRY(hipStreamWaitValue32(rs, c->drain_signal, c->launch_seq + 1u - back, hipStreamWaitValueGte, 0xFFFFFFFFu));
+            unsigned target = c->launch_seq + 1u > back ? c->launch_seq + 1u - back : 0u;
+            if (target < c->last_full_seq) target = c->last_full_seq;
+            if (c->drain_signal && c->drain_signalled && target > 0u)
+                HIP_TRY(hipStreamWaitValue32(rs, c->drain_signal, target, hipStreamWaitValueGte, 0xFFFFFFFFu));
         } else if (c->last_set != 0) {
             // back to the single copy: whoever reads pixels this launch does not write (moving camera at half render
             // scale) expects the last sample of the last launch in the canonical buffers
@@ -847,7 +890,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         HIP_TRY(hipEventRecord(a, rs));
         const unsigned seq = c->launch_seq++;
         // test hook (tests/test_gpu_pipeline.py): launch number VRT_TEST_FAIL_LAUNCH (read at vrt_create) is reported as failed instead of queued
-        if (c->test_fail_launch >= 0 && (unsigned)c->test_fail_launch == seq) return fail(VRT_E_DEVICE, "injected launch failure (VRT_TEST_FAIL_LAUNCH)");
+        if (c->knobs.fail_launch >= 0 && (unsigned)c->knobs.fail_launch == seq) return fail(VRT_E_DEVICE, "injected launch failure (VRT_TEST_FAIL_LAUNCH)");
         PrimaryRecord* prim = nullptr;  // fused samples share their camera rays through this table (vrt_pool.h)
         if (c->pooled && g > 1 && (!instr || c->count_as_timed)) {  // counting the reference's work: every camera ray is walked
             const int which = overlapped ? lane_of : 0;
@@ -856,9 +899,10 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         }
         const int blocks = lone ? c->render_blocks : (c->render_blocks / c->grid_div + 7) & ~7;  // whole rounds of the 8 XCDs
         if (c->pooled) HIP_TRY(launch_render_pool(rs, c->cfg.grid_res, restir, instr, blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch[lane_of - 1] : c->d_pool_scratch, c->drain_signal, prim, culling(c), c->dense_grid));
-        else HIP_TRY(launch_render(rs, c->cfg.grid_res, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g));
+        else HIP_TRY(launch_render(rs, c->cfg.grid_res, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g, c->knobs.chunk));
         c->drain_signalled = c->pooled && c->drain_signal != nullptr;
         c->prev_launch_full = blocks == c->render_blocks;
+        if (c->prev_launch_full && c->pooled) c->last_full_seq = seq + 1u;
         HIP_TRY(hipEventRecord(b, rs));
         if (overlapped) {
             HIP_TRY(hipEventRecord(c->ev_r[set], rs));
@@ -1029,6 +1073,7 @@ static int fetch_async(vrt_ctx* c, void* out, int slot, int what /* 0 HDR, 1 LDR
     const bool ldr = what != 0;
     if (!c || !out || slot < 0 || slot >= VRT_FETCH_SLOTS) return fail(VRT_E_INVALID, "bad argument (slot must be 0..3)");
     if (ldr && !c->have_cam) return fail(VRT_E_STATE, "vrt_set_camera has not been called");
+    if (c->fetch_valid[slot]) return fail(VRT_E_STATE, "this slot's previous fetch has not been collected (vrt_fetch_wait)");
     HIP_TRY(hipSetDevice(c->device));
     if (what == 2 && !c->d_ldr8 && dalloc(&c->d_ldr8, c->npix) != hipSuccess) { c->d_ldr8 = nullptr; return fail(VRT_E_DEVICE, "no memory for the 8-bit image"); }
     if (ensure_fetch_stream(c) != VRT_OK) return VRT_E_DEVICE;
@@ -1064,7 +1109,7 @@ int vrt_fetch_wait(vrt_ctx* c, int slot) {
     if (c->drain_signal && c->drain_signalled) {
         const double t0 = now_s();
         while (hipEventQuery(c->ev_fetch[slot]) == hipErrorNotReady) {
-            if (now_s() - t0 > 2.0) { release_gate(c); break; }
+            if (now_s() - t0 > c->knobs.gate_watchdog_s) { release_gate(c); break; }
             std::this_thread::yield();
         }
         (void)hipGetLastError();
@@ -1096,7 +1141,7 @@ int vrt_set_hdr_targets(vrt_ctx* c, void* const* device_ptrs, int n) {
     if (!c || n < 0 || (n > 0 && !device_ptrs)) return fail(VRT_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     c->hdr_targets.assign(device_ptrs, device_ptrs + n);
-    c->hdr_targets_written = 0;
+    c->hdr_targets_written = c->hdr_targets_committed = 0;
     return VRT_OK;
 }
 int vrt_hdr_targets_written(vrt_ctx* c, uint64_t* count) {

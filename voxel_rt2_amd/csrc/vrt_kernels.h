@@ -39,7 +39,7 @@ hipError_t launch_prepare(hipStream_t st, int grid_res, const int8_t* mat, const
                           float* cull /*[6]: cull_ray()'s box, vrt_trace.h*/);
 hipError_t query_render_residency(int grid_res, bool restir, bool instr, int* blocks_per_cu);
 hipError_t launch_render(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
-                         const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples);
+                         const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, int chunk_override);
 // pooled schedule (vrt_pool.h).  `cold` holds pool_scratch_bytes(grid_res, restir, n_blocks) bytes.
 hipError_t query_render_pool_residency(int grid_res, bool restir, bool instr, int* blocks_per_cu);
 int pool_waves_per_block(int grid_res);

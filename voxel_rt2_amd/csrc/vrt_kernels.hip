@@ -693,8 +693,11 @@ __global__ __launch_bounds__(256, (PHASE == 1 ? VRT_GRIS_MIN_WAVES_A : PHASE == 
 
 // split pass, before its two kernels: masks of accepted and of live taps per pixel (gris_classify_pixel).  Same tiling as k_gris:
 // a wave is one 8x8 tile of the tap-angle hash.
+#ifndef VRT_CLASSIFY_MIN_WAVES
+#define VRT_CLASSIFY_MIN_WAVES 4
+#endif
 template <bool INSTR>
-__global__ __launch_bounds__(256) void k_gris_classify(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r_first, int r1, int tiles_x, int band_w) {
+__global__ __launch_bounds__(256, VRT_CLASSIFY_MIN_WAVES) void k_gris_classify(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r_first, int r1, int tiles_x, int band_w) {
     __shared__ float s_cs[4][64];
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int bx = xcd * band_w + slot % band_w, by = slot / band_w;
@@ -719,7 +722,7 @@ __global__ __launch_bounds__(256) void k_gris_prepare(FrameParams fp, SceneData 
 }
 __global__ void k_mat_derived(const float* mats, float* mats_x) {
     const int id = threadIdx.x;
-    if (id < 128) store_mat_derived(mats_x, id, mat_derive(load_material(mats, id)));
+    if (id < 128) { const Material m = load_material(mats, id); store_mat_derived(mats_x, id, mat_derive(m), material_unit_range(m)); }
 }
 
 // ---- temporal accumulation + presentation ------------------------------------------------------
@@ -830,7 +833,7 @@ hipError_t query_render_residency(int grid_res, bool restir, bool instr, int* bl
 }
 
 hipError_t launch_render(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
-                         const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples) {
+                         const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, int chunk_override) {
     // sixteen sets of heads rotate: launch k counts on set k % 16 and zeroes set (k + 8) % 16 -- up to four launches are in
     // flight together (vrt_accumulate) and none of their sets may be touched; launch k + 8 runs on launch k's stream (the
     // pipeline is 2 or 4 streams deep), so its set is clean before it starts whatever the other streams do
@@ -839,9 +842,8 @@ hipError_t launch_render(hipStream_t st, int grid_res, bool restir, bool instr, 
     dim3 g(n_blocks), b(VRT_RENDER_THREADS);
     // pixels a wave reserves per atomic: whole 8x8 tiles.  One tile keeps the tail short (measured: 192-pixel chunks
     // cost 13 % at 1080p on the sparse scene) and still cuts the atomic rate ~3x against per-refill atomics, which
-    // is what the dense 4K frame needed (67 -> 22 dequeues/us, 5.9 -> 4.8 ms).  VRT_CHUNK overrides for experiments.
-    unsigned chunk = 64u;
-    if (const char* e = getenv("VRT_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 4096) chunk = (unsigned)(v / 64 * 64); }
+    // is what the dense 4K frame needed (67 -> 22 dequeues/us, 5.9 -> 4.8 ms).  chunk_override: development builds (VRT_CHUNK).
+    const unsigned chunk = chunk_override > 0 ? (unsigned)chunk_override : 64u;
     VRT_BY_GRID(grid_res, VRT_BY_2(restir, instr, hipLaunchKernelGGL((k_render<G, A, B>), g, b, 0, st, fp, sc, out, work_counter, next_counter, chunk, n_samples)));
     VRT_LAUNCH_CHECK();
     return hipSuccess;

@@ -55,9 +55,14 @@ enum {  // LDS columns of a slot (dwords)
     PF_COUNT = 25
 };
 enum { PC_NEE_D = 0, PC_NEE_S = 3, PC_ALBEDO = 6, PC_PPOS = 9, PC_INVPDF = 12, PC_MAT = 13, PC_COUNT = 16,   // scratch line
-       // ReSTIR: the reconnection state of PathRestir (vrt_path.h) follows -- it changes at every vertex, so the line is
-       // read and written by every SHADE / ESCAPE of a path, through L2
-       PC_RS = 16, PC_COUNT_RESTIR = 48 };
+       // ReSTIR: the reconnection state of PathRestir (vrt_path.h) follows.  Each of its fields is produced at ONE depth (the
+       // first light sample at the primary vertex, the reconnection vertex at depth 1, its outgoing direction at depth 2) except
+       // the two running values behind the reconnection vertex: a SHADE / ESCAPE therefore reads and writes only what its depth
+       // touches (restir_cold_*), and the whole line is read once, when the path ends
+       PC_RS = 16, PC_COUNT_RESTIR = 48,
+       // offsets behind PC_RS
+       RS_THR = 0, RS_FIRST_DIR = 3, RS_FIRST_LIGHT_DIR = 6, RS_RC_POS = 9, RS_RC_NORMAL = 12, RS_RC_INC_DIR = 15, RS_RC_INC_L = 18,
+       RS_RC_NEE_DIR = 21, RS_RC_MAT = 24, RS_FIRST_LIGHT_PDF = 25, RS_RC_LOBE = 26 };
 template <bool RESTIR> struct ColdLine { static constexpr int count = RESTIR ? (int)PC_COUNT_RESTIR : (int)PC_COUNT; };
 
 // A slot's column in the pool: field f lives at base[f * stride].
@@ -147,6 +152,7 @@ VRT_DEV void path_load_hot(const SlotRef& s, Path<RESTIR>& p) {
     p.refl_dist = s.f(PF_REFL);
     path_cold_defaults(p);
 }
+// (paths without ReSTIR: written once, at the primary vertex, read once, when the path ends; with ReSTIR: restir_cold_* below)
 template <bool RESTIR>
 VRT_DEV void path_store_cold(uint32_t* line, const Path<RESTIR>& p) {
     line[PC_NEE_D] = dm_f2u(p.nee_d.x); line[PC_NEE_D + 1] = dm_f2u(p.nee_d.y); line[PC_NEE_D + 2] = dm_f2u(p.nee_d.z);
@@ -155,14 +161,6 @@ VRT_DEV void path_store_cold(uint32_t* line, const Path<RESTIR>& p) {
     line[PC_PPOS] = dm_f2u(p.primary_pos.x); line[PC_PPOS + 1] = dm_f2u(p.primary_pos.y); line[PC_PPOS + 2] = dm_f2u(p.primary_pos.z);
     line[PC_INVPDF] = dm_f2u(p.first_invpdf);
     line[PC_MAT] = p.primary_mat_info;
-    if constexpr (RESTIR) {
-        uint32_t* r = line + PC_RS;
-        const f3* v[8] = {&p.rs.thr_after_rc, &p.rs.first_dir, &p.rs.first_light_dir, &p.rs.rc_pos, &p.rs.rc_normal, &p.rs.rc_incident_dir,
-                          &p.rs.rc_incident_L, &p.rs.rc_nee_dir};
-#pragma unroll
-        for (int k = 0; k < 8; k++) { r[3 * k] = dm_f2u(v[k]->x); r[3 * k + 1] = dm_f2u(v[k]->y); r[3 * k + 2] = dm_f2u(v[k]->z); }
-        r[24] = p.rs.rc_mat_info; r[25] = dm_f2u(p.rs.first_light_bsdf_pdf); r[26] = (uint32_t)p.rs.rc_lobe;
-    }
 }
 template <bool RESTIR>
 VRT_DEV void path_load_cold(const uint32_t* line, Path<RESTIR>& p) {
@@ -172,13 +170,52 @@ VRT_DEV void path_load_cold(const uint32_t* line, Path<RESTIR>& p) {
     p.primary_pos = mk3(dm_u2f(line[PC_PPOS]), dm_u2f(line[PC_PPOS + 1]), dm_u2f(line[PC_PPOS + 2]));
     p.first_invpdf = dm_u2f(line[PC_INVPDF]);
     p.primary_mat_info = line[PC_MAT];
-    if constexpr (RESTIR) {
-        const uint32_t* r = line + PC_RS;
-        f3* v[8] = {&p.rs.thr_after_rc, &p.rs.first_dir, &p.rs.first_light_dir, &p.rs.rc_pos, &p.rs.rc_normal, &p.rs.rc_incident_dir,
-                    &p.rs.rc_incident_L, &p.rs.rc_nee_dir};
-#pragma unroll
-        for (int k = 0; k < 8; k++) *v[k] = mk3(dm_u2f(r[3 * k]), dm_u2f(r[3 * k + 1]), dm_u2f(r[3 * k + 2]));
-        p.rs.rc_mat_info = r[24]; p.rs.first_light_bsdf_pdf = dm_u2f(r[25]); p.rs.rc_lobe = (int)r[26];
+}
+
+// ---- the ReSTIR part of the scratch line, by depth ------------------------------------------------------------------------
+// Which PathRestir field a vertex at depth d produces (path_shade, vrt_path.h): d = 0: first_light_bsdf_pdf, first_light_dir
+// (and the primary-vertex words PC_NEE_D .. PC_MAT); d = 1: first_dir, rc_pos, rc_normal, rc_mat_info, rc_nee_dir, rc_lobe
+// (an escape at depth 1: rc_pos, rc_incident_L -- and the path ends); d = 2: rc_incident_dir; d >= 2: thr_after_rc and
+// rc_incident_L, the only fields a vertex READS.  A path that goes on from depth 1 found a surface there, so it arrives at
+// depth 2 with thr_after_rc = 1 and rc_incident_L = 0 -- path_begin's values, which path_load_hot() has already put in `p`.
+VRT_DEV void cold_st3(uint32_t* at, f3 v) { at[0] = dm_f2u(v.x); at[1] = dm_f2u(v.y); at[2] = dm_f2u(v.z); }
+VRT_DEV f3 cold_ld3(const uint32_t* at) { return mk3(dm_u2f(at[0]), dm_u2f(at[1]), dm_u2f(at[2])); }
+// before the vertex at `depth` is shaded: what it reads
+VRT_DEV void restir_cold_load_running(const uint32_t* line, Path<true>& p, int depth) {
+    if (depth >= 3) { p.rs.thr_after_rc = cold_ld3(line + PC_RS + RS_THR); p.rs.rc_incident_L = cold_ld3(line + PC_RS + RS_RC_INC_L); }
+}
+// the path goes on: what the vertex at `depth` produced
+VRT_DEV void restir_cold_store(uint32_t* line, const Path<true>& p, int depth) {
+    uint32_t* r = line + PC_RS;
+    if (depth == 0) {
+        cold_st3(line + PC_NEE_D, p.nee_d); cold_st3(line + PC_NEE_S, p.nee_s); cold_st3(line + PC_ALBEDO, p.primary_albedo);
+        cold_st3(line + PC_PPOS, p.primary_pos);
+        line[PC_INVPDF] = dm_f2u(p.first_invpdf); line[PC_MAT] = p.primary_mat_info;
+        cold_st3(r + RS_FIRST_LIGHT_DIR, p.rs.first_light_dir);
+        r[RS_FIRST_LIGHT_PDF] = dm_f2u(p.rs.first_light_bsdf_pdf);
+    } else if (depth == 1) {
+        cold_st3(r + RS_FIRST_DIR, p.rs.first_dir); cold_st3(r + RS_RC_POS, p.rs.rc_pos); cold_st3(r + RS_RC_NORMAL, p.rs.rc_normal);
+        cold_st3(r + RS_RC_NEE_DIR, p.rs.rc_nee_dir);
+        r[RS_RC_MAT] = p.rs.rc_mat_info; r[RS_RC_LOBE] = (uint32_t)p.rs.rc_lobe;
+    } else {
+        cold_st3(r + RS_THR, p.rs.thr_after_rc); cold_st3(r + RS_RC_INC_L, p.rs.rc_incident_L);
+        if (depth == 2) cold_st3(r + RS_RC_INC_DIR, p.rs.rc_incident_dir);
+    }
+}
+// the path ends at `depth` (> 0): everything earlier vertices produced, for path_finish / restir_finish
+VRT_DEV void restir_cold_load_rest(const uint32_t* line, Path<true>& p, int depth) {
+    const uint32_t* r = line + PC_RS;
+    p.nee_d = cold_ld3(line + PC_NEE_D); p.nee_s = cold_ld3(line + PC_NEE_S);
+    p.primary_albedo = cold_ld3(line + PC_ALBEDO); p.primary_pos = cold_ld3(line + PC_PPOS);
+    p.first_invpdf = dm_u2f(line[PC_INVPDF]);
+    p.primary_mat_info = line[PC_MAT];
+    p.rs.first_light_dir = cold_ld3(r + RS_FIRST_LIGHT_DIR);
+    p.rs.first_light_bsdf_pdf = dm_u2f(r[RS_FIRST_LIGHT_PDF]);
+    if (depth >= 2) {
+        p.rs.first_dir = cold_ld3(r + RS_FIRST_DIR); p.rs.rc_pos = cold_ld3(r + RS_RC_POS); p.rs.rc_normal = cold_ld3(r + RS_RC_NORMAL);
+        p.rs.rc_nee_dir = cold_ld3(r + RS_RC_NEE_DIR);
+        p.rs.rc_mat_info = r[RS_RC_MAT]; p.rs.rc_lobe = (int)r[RS_RC_LOBE];
+        if (depth >= 3) p.rs.rc_incident_dir = cold_ld3(r + RS_RC_INC_DIR);
     }
 }
 
@@ -293,14 +330,18 @@ VRT_DEV int pool_shade(const FrameParams& fp, const SceneData& sc, const PyrT& P
                     normal_decode(b >> 20), (int)s.u(PF_ITERS), tr);
         hit_voxel<false, PyrT::G>(fp, sc, world_to_voxel<PyrT::G>(p.pos), p.d, tr, h, ts);
     }
-    if constexpr (RESTIR) { if (depth > 0) path_load_cold(cold_line, p); }  // the reconnection state is updated at every vertex
+    if constexpr (RESTIR) restir_cold_load_running(cold_line, p, depth);
     const bool done = path_shade<RESTIR, KIND, BLACK_SUN>(fp, sc, P, out, local_idx, p, h, ts);
     if (done) {
-        if constexpr (!RESTIR) { if (depth > 0) path_load_cold(cold_line, p); }
+        if (depth > 0) {
+            if constexpr (RESTIR) restir_cold_load_rest(cold_line, p, depth);
+            else path_load_cold(cold_line, p);
+        }
         path_finish<RESTIR>(fp, sc, out, local_idx, p, ts);
         return SLOT_EMPTY;
     }
-    if (RESTIR || depth == 0) path_store_cold(cold_line, p);
+    if constexpr (RESTIR) restir_cold_store(cold_line, p, depth);
+    else { if (depth == 0) path_store_cold(cold_line, p); }
     path_store_hot(s, p);
     return pool_launch_ray<PyrT::G, PyrT::cull>(fp, sc.cull, s, p.pos, p.d, ts);
 }

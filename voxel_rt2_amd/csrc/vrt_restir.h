@@ -147,9 +147,18 @@ VRT_DEV MatDerived load_mat_derived(const float* mats_x, int id) {
     x.ax = p[0]; x.ay = p[1]; x.cc_alpha = p[2]; x.w_d = p[3]; x.w_s = p[4]; x.w_c = p[5];
     return x;
 }
-VRT_DEV void store_mat_derived(float* mats_x, int id, const MatDerived& x) {
+VRT_DEV void store_mat_derived(float* mats_x, int id, const MatDerived& x, float unit_range = 0.0f) {
     float* p = mats_x + 8 * id;
-    p[0] = x.ax; p[1] = x.ay; p[2] = x.cc_alpha; p[3] = x.w_d; p[4] = x.w_s; p[5] = x.w_c; p[6] = 0.0f; p[7] = 0.0f;
+    p[0] = x.ax; p[1] = x.ay; p[2] = x.cc_alpha; p[3] = x.w_d; p[4] = x.w_s; p[5] = x.w_c; p[6] = unit_range; p[7] = 0.0f;
+}
+// 1: every parameter of the material row that the BSDF evaluation reads lies in [0, 1] (true of the whole default CSV).  What
+// shift_is_constant() below needs to BOUND a BSDF value without evaluating it; rows outside are simply always evaluated.
+VRT_DEV float material_unit_range(const Material& m) {
+    const float q[10] = {m.subsurface, m.metallic, m.specular, m.specular_tint, m.roughness, m.anisotropic, m.sheen, m.sheen_tint, m.clearcoat,
+                         m.clearcoat_gloss};
+    bool ok = true;
+    for (int k = 0; k < 10; k++) ok = ok && q[k] >= 0.0f && q[k] <= 1.0f;
+    return ok ? 1.0f : 0.0f;
 }
 
 // pathtracer.py:672-812: shift `src`'s sample to the primary vertex at dst_pos whose shading frame is `ds`
@@ -166,10 +175,11 @@ struct RcPre {
     DirTerms inc, nee;   // dir_terms() of rc_incident_dir and rc_nee_dir at the reconnection vertex
 };
 // The Jacobian shift_sample() returns (out_jac), alone: :681-688 and :789-803 need the two primary vertices and three fields of the sample.
-VRT_DEV float shift_jacobian(f3 dst_pos, f3 dst_normal, f3 rc_pos, f3 rc_normal, float cached_jac) {
+VRT_DEV float shift_jacobian(f3 dst_pos, f3 dst_normal, f3 rc_pos, f3 rc_normal, float cached_jac, float* dst_nl = nullptr) {
     const bool escape = near_zero3(rc_normal);
     const f3 to_rc = escape ? rc_pos : norm3(rc_pos - dst_pos);
     float passed = 1.0f;
+    if (dst_nl) *dst_nl = dot3(dst_normal, to_rc);   // the destination's n.l as bsdf_eval_pdf() will compute it
     if (dot3(dst_normal, to_rc) < 1e-5f || (!escape && dot3(rc_normal, -to_rc) < 1e-5f)) passed = 0.0f;
     float jac = 1.0f;
     if (!escape) {
@@ -179,6 +189,25 @@ VRT_DEV float shift_jacobian(f3 dst_pos, f3 dst_normal, f3 rc_pos, f3 rc_normal,
     }
     if (jac < 0.0f || dm_isnan(jac) || dm_isinf(jac)) jac = 0.0f;
     return jac * passed;
+}
+// Is the CENTRE -> NEIGHBOUR shift of the first tap loop (:917-931) a known constant, so that it need not be evaluated?
+// Its term is 1 - cw, cw = (L j M_n) / (L j M_n + X), with j the shift's Jacobian, L = lum(BSDF_dst cos contrib), M_n the
+// neighbour's M and X = lum(F_c) M_c / max_taps a value of the centre alone.  With j = 0 and L and M_n FINITE, L j M_n is a
+// zero and the term is 1 - 0 / X whatever the shift computes: a constant of the pixel.  j is shift_jacobian() (the same
+// expressions as in shift_sample, so the same bits); M_n is in the record; L is finite when
+//   * the destination's n.l is not > 0 -- or its n.v is not: eval_lobes' `front` test fails and the BSDF is an exact zero --, or
+//   * n.l >= 1e-5 and n.v >= 1e-5 and the destination's material row lies in [0, 1] (material_unit_range): then every factor of
+//     the evaluation is bounded -- |l + v| >= n.l + n.v >= 2e-5; the anisotropic GGX term <= 1 / (pi 1e-6 (1 / 10.3)^2) < 4e7
+//     (alphas in [1e-3, 3.2]); each Smith term <= 1 / (2 * 1e-5); gtr1 < 4e4 (its t >= alpha^2 - 3e-7 > 0 for alpha >= 1e-3);
+//     Fresnel and colour factors <= 1; 1 / (n.l + n.v) <= 5e4 -- so |BSDF| < 1e18, times cos <= 1, times contrib, a sum of
+//     firefly-clamped terms and an albedo within [0, 601]: finite.
+// Everything else (a grazing 0 < n.l < 1e-5, a material row outside [0, 1], a non-finite M) is evaluated as before.  `dst_ok` is
+// the destination's share of the test, worked out once per pixel by the prepare pass: !(n.v > 0) || (n.v >= 1e-5 && unit range).
+VRT_DEV bool shift_is_constant(f3 dst_pos, f3 dst_normal, bool dst_ok, float dst_M, f3 rc_pos, f3 rc_normal, float cached_jac) {
+    float nl;
+    if (shift_jacobian(dst_pos, dst_normal, rc_pos, rc_normal, cached_jac, &nl) != 0.0f) return false;
+    if (!(dst_M >= 0.0f && dst_M < DM_INF)) return false;
+    return !(nl > 0.0f) || (nl >= 1e-5f && dst_ok);
 }
 VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const float* mats_x, f3 dst_pos, const Surf& ds, const SurfShared& dsc,
                           const Reservoir& src, f3 rc_ty, f3 src_sky_t, const RcPre& pre, f3& out_d, f3& out_s, float& out_jac, TraceStats& ts) {
@@ -294,6 +323,7 @@ struct alignas(16) GrisTest {
     f3 n; float dist;        // = GrisGeo: the geometric test (:912)
     f3 rc_pos; float jac;    // = GrisSrc: what shift_jacobian() needs of the sample
     f3 rc_normal; float M;
+    f3 x1; uint32_t dst_ok;  // = GrisGeo: the pixel as the destination of the centre's sample (shift_is_constant)
 };
 struct GrisBuffers {
     GrisGeo* geo;            // [rows of the launch][W], written by the prepare pass
@@ -327,11 +357,13 @@ VRT_DEV void gris_prepare_pixel(const FrameParams& fp, const SceneData& sc, cons
     f3 tx;
     ortho_basis(g.n, tx, g.ty);
     g.pad = 0u;
+    bool dst_ok;
     {   // the pixel's own shading point as every neighbour's shift will set it up (gris_pixel, first tap loop)
         int id;
         const Material m = material_from_bits(sc.mats, g.mat, id);
         Surf ds;
         surf_set(ds, m, load_mat_derived(gb.mats_x, id), g.n, g.v, cross3(g.n, g.ty), g.ty);
+        dst_ok = !(ds.n_v > 0.0f) || (ds.n_v >= 1e-5f && gb.mats_x[8 * (id & 127) + 6] != 0.0f);   // shift_is_constant()
         const SurfShared c = surf_shared(ds, true, true, true);
         g.base = m.base; g.fv = c.fv; g.lambert = c.lambert; g.g_v = c.g_v; g.sheen_col = c.sheen_col; g.gc_v = c.gc_v;
         g.spec_col = c.spec_col; g.pad3 = 0u;
@@ -362,6 +394,7 @@ VRT_DEV void gris_prepare_pixel(const FrameParams& fp, const SceneData& sc, cons
     gb.src[idx] = s;
     GrisTest t;
     t.n = g.n; t.dist = g.dist; t.rc_pos = s.rc_pos; t.jac = s.jac; t.rc_normal = s.rc_normal; t.M = g.M;
+    t.x1 = g.x1; t.dst_ok = dst_ok ? 1u : 0u;
     gb.tst[idx] = t;
 }
 VRT_DEV void gris_load_src(Reservoir& r, f3& rc_ty, f3& sky_t, RcPre& pre, const GrisSrc& s) {
@@ -406,6 +439,9 @@ VRT_DEV bool gris_tap(const FrameParams& fp, const GrisTaps& taps, int u, int v,
     return !(tx < 0 || ty < 0 || tx >= fp.W || ty >= fp.H);
 }
 
+#ifndef VRT_CLASSIFY_BATCH
+#define VRT_CLASSIFY_BATCH 4
+#endif
 // Split pass, before its two kernels: which taps pass the geometric test (:883-912, the mask both kernels walk), and which of
 // those carry a sample whose shift into this pixel's domain has a Jacobian that is not zero (see the resampling loop of
 // gris_pixel).  Needs one 48-byte record per tap and no BSDF: a kernel of 6 waves per SIMD instead of 3.
@@ -420,26 +456,31 @@ VRT_DEV void gris_classify_pixel(const FrameParams& fp, const GrisBuffers& gb, c
     const f3 cx1 = cg->x1, cn1 = cg->n;
     const float cdist = cg->dist;
     if (near_zero3(cx1)) return;
-    unsigned accepted = 0u, live = 0u;
+    unsigned accepted = 0u, live = 0u, live_first = 0u;
     float dead_M = 0.0f;
-    // four taps at a time, their records fetched before any is looked at: the loop is a chain of dependent cache misses otherwise
+    // the centre's own sample, for its shifts into the neighbours' domains (first kernel)
+    const GrisTest ct = gb.tst[idx];
+    const bool c_counts_sky = fp.use_sky == 1 && !near_zero3(ct.rc_normal) && !near_zero3(gb.src[idx].rc_nee_dir);
+    // VRT_CLASSIFY_BATCH taps at a time, their records fetched before any is looked at: the loop is a chain of dependent cache misses otherwise
     // (a tap outside the image fetches the pixel's own record, which is not used)
-    for (int i0 = 0; i0 < max_taps; i0 += 4) {
-        GrisTest rec[4];
-        int at[4];
+    for (int i0 = 0; i0 < max_taps; i0 += VRT_CLASSIFY_BATCH) {
+        GrisTest rec[VRT_CLASSIFY_BATCH];
+        int at[VRT_CLASSIFY_BATCH];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < VRT_CLASSIFY_BATCH; k++) {
             int tx, ty;
             const bool in = i0 + k < max_taps && gris_tap(fp, taps, u, v, i0 + k, radius_shift, max_radius, max_taps, tx, ty);
             at[k] = in ? (ty - fp.row0) * fp.W + tx : -1;
             rec[k] = gb.tst[in ? at[k] : idx];
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < VRT_CLASSIFY_BATCH; k++) {
             if (at[k] < 0) continue;
             const GrisTest& nt = rec[k];
             if (dm_abs(nt.dist - cdist) > 0.1f * cdist || dot3(cn1, nt.n) < 0.5f) continue;  // :912
             accepted |= 1u << (i0 + k);
+            if (!shift_is_constant(nt.x1, nt.n, nt.dst_ok != 0u, nt.M, ct.rc_pos, ct.rc_normal, ct.jac)) live_first |= 1u << (i0 + k);
+            else if (c_counts_sky) ts.sky_lookups += 1u;   // (the lookup the reference makes inside the shift that is not evaluated)
             if (shift_jacobian(cx1, cn1, nt.rc_pos, nt.rc_normal, nt.jac) != 0.0f) live |= 1u << (i0 + k);
             else {
                 dead_M += nt.M;
@@ -451,6 +492,7 @@ VRT_DEV void gris_classify_pixel(const FrameParams& fp, const GrisBuffers& gb, c
     gb.geo[idx].pad = accepted;
     gb.src[idx].pad0 = live;
     gb.src[idx].pad1 = dm_f2u(dead_M);
+    gb.src[idx].pad2 = live_first;
 }
 
 // pathtracer.py:815-989, called as spatial_GRIS(0, 24.0, 32, 1) (:1313)
@@ -518,8 +560,25 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         if (dm_abs(ndist - cdist) > 0.1f * cdist || dot3(cn1, nn1) < 0.5f) continue;  // :912
         accepted |= 1u << i;
     }
-    for (unsigned m = (PHASE == 2) ? 0u : accepted; m != 0u; m &= m - 1u) {
+    // Split pass: the taps whose centre -> neighbour shift is a known constant (shift_is_constant(): a zero Jacobian, two in three
+    // in a scene open to the sky) are not evaluated.  Their term 1 - 0 / X is summed where the tap stands in the order -- the
+    // sum is a float sum, its order is the reference's -- so a lane's trips are its taps that NEED a shift, and a wave's its
+    // busiest pixel's.
+    unsigned walk = (PHASE == 2) ? 0u : accepted, pending = 0u;
+    float const_term = 0.0f;
+    if (PHASE == 1) {
+        walk = accepted & gb.src[idx].pad2;
+        pending = accepted;
+        float cw = 0.0f;                                            // c_p_hat * nb_M with c_p_hat = L * 0
+        cw /= 0.0f + lum(center.z.F) * center.M / (float)max_taps;
+        const_term = 1.0f - cw;
+    }
+    for (unsigned m = walk; m != 0u; m &= m - 1u) {
         const int i = __builtin_ctz(m);
+        if (PHASE == 1) {
+            for (int k = __builtin_popcount(pending & ((1u << i) - 1u)); k > 0; k--) canonical_mis += const_term;
+            pending &= ~(((1u << i) - 1u) | (1u << i));
+        }
         int tx, ty;
         if (PHASE == 1) (void)gris_tap(fp, taps, u, v, i, radius_shift, max_radius, max_taps, tx, ty);
         else {
@@ -547,6 +606,7 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     // the second the centre's shading point and the output reservoir -- neither needs the other's, so the shading point is
     // built only now and the centre's sample is read again after the second loop instead of being kept across it.
     if (PHASE == 1) {   // what the second kernel needs of the first
+        for (int k = __builtin_popcount(pending); k > 0; k--) canonical_mis += const_term;
         gb.geo[idx].pad3 = dm_f2u(canonical_mis);
         return;
     }

@@ -241,9 +241,10 @@ class Renderer(VoxelStore):
         self._s.fetch_ldr8_async(self._present[slot & 1], slot & 1)
 
     def present_wait(self, slot=0):
-        """rgba8 [H, W, 4] (row 0 = bottom) of the frame present_async(slot) was called on."""
+        """rgba8 [H, W, 4] (row 0 = bottom) of the frame present_async(slot) was called on.  A copy: the page-locked buffer
+        behind it is reused two frames later and is freed when the session closes."""
         self._s.fetch_wait(slot & 1)
-        return self._present[slot & 1]
+        return self._present[slot & 1].copy()
 
     def stats(self):
         return self._s.stats()
