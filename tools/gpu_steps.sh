@@ -10,6 +10,7 @@
 #   refidx          tools/ref_indexing_diff.py on configs 4 and 5 (GPU)
 #   trace:CASE      rocprofv3 --kernel-trace --stats of bench_scenes.py CASE (CASE = bench: the bench command, config 2)
 #   pmc:CASE        tools/pmc.sh CASE + summary
+#   diag:NAME:ARGS       tools/diag_regions.py ARGS (comma separated) with build_variants/libvrt_NAME.so (a -DVRT_DIAG_REGIONS build)
 #   variant:NAME:CASES   tools/bench_scenes.py CASES (comma separated) with build_variants/libvrt_NAME.so (built beforehand: tools/build_variant.sh)
 set -o pipefail
 TAG=$1; shift
@@ -54,6 +55,10 @@ for l in open('$O/scenes${arg:+_}${arg//,/_}.jsonl'):
 import json
 for l in open('$O/variant_$vname.jsonl'):
     d=json.loads(l); print('  [$vname]', d.get('name'), d.get('mpaths_per_s'), {k:v for k,v in d.items() if k.endswith('_ms')})" ;;
+    diag)   # diag:NAME:ARGS -> tools/diag_regions.py ARGS with build_variants/libvrt_NAME.so (a -DVRT_DIAG_REGIONS build)
+      IFS=: read -r vname dargs <<< "$arg"
+      VRT_LIB_PATH=$GRAFT_REPO_ROOT/build_variants/libvrt_$vname.so timeout -k 10 600 python tools/diag_regions.py ${dargs//,/ } > $O/diag_$vname.txt 2> $O/diag_$vname.err || { tail -5 $O/diag_$vname.err; fail diag:$vname $?; }
+      cat $O/diag_$vname.txt ;;
     *) echo "unknown step $step"; exit 64 ;;
   esac
 done

@@ -95,6 +95,7 @@ struct vrt_ctx {
     hipStream_t stream = nullptr;
     bool owns_stream = true;
     int n_cu = 0, render_blocks = 0;
+    int render_blocks_d12 = 0;        // ... of the twelve-wave geometry a dense 128^3 grid renders on (k_render_pool_dense12)
     int reserved_cus = 0;             // CUs' worth of workgroup slots the persistent render grid leaves free (vrt_reserve_cus)
     bool pooled = false;              // render through k_render_pool (vrt_pool.h) instead of k_render
     uint32_t* d_pool_scratch = nullptr;
@@ -682,7 +683,7 @@ static bool ensure_overlap(vrt_ctx* c, int g) {   // g: samples of the launch th
              dalloc(&c->alt_gb_mat[s], n) == hipSuccess;
     for (int s = 0; s < c->n_streams && ok; s++) ok = hipStreamCreateWithFlags(&c->rstream[s], hipStreamNonBlocking) == hipSuccess;
     for (int s = 0; s < c->n_streams - 1 && ok; s++)
-        ok = hipMalloc((void**)&c->alt_pool_scratch[s], pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks)) == hipSuccess;
+        ok = hipMalloc((void**)&c->alt_pool_scratch[s], pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks, c->render_blocks_d12)) == hipSuccess;
     for (int s = 0; s < n_sets && ok; s++)
         ok = hipEventCreateWithFlags(&c->ev_r[s], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_t[s], hipEventDisableTiming) == hipSuccess;
@@ -776,15 +777,21 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         int cus = c->n_cu - c->reserved_cus;
         if (cus < 8) cus = c->n_cu < 8 ? c->n_cu : 8;
         c->render_blocks = per_cu * cus;   // (abort_pipeline zeroes it again if an allocation below fails)
+        c->render_blocks_d12 = 0;
+        if (pooled && !restir && c->cfg.grid_res == 128) {
+            int per_cu12 = 0;
+            HIP_TRY(query_render_pool_dense12_residency(instr, &per_cu12));
+            c->render_blocks_d12 = (per_cu12 < 1 ? 1 : per_cu12) * cus;
+        }
         c->pooled = pooled;
         if (pooled) {
             HIP_TRY(sync_guarded(c, c->stream));
             if (c->d_pool_scratch) { HIP_TRY(hipFree(c->d_pool_scratch)); c->d_pool_scratch = nullptr; }
-            HIP_TRY(hipMalloc((void**)&c->d_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks)));
+            HIP_TRY(hipMalloc((void**)&c->d_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks, c->render_blocks_d12)));
             if (c->overlap_ready) {  // the other render streams' scratch follows
                 for (int s = 0; s < c->n_streams - 1; s++) {
                     if (c->alt_pool_scratch[s]) { HIP_TRY(hipFree(c->alt_pool_scratch[s])); c->alt_pool_scratch[s] = nullptr; }
-                    HIP_TRY(hipMalloc((void**)&c->alt_pool_scratch[s], pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks)));
+                    HIP_TRY(hipMalloc((void**)&c->alt_pool_scratch[s], pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks, c->render_blocks_d12)));
                 }
             }
         }
@@ -897,11 +904,13 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             if (!c->d_prim_cache[which] && dalloc(&c->d_prim_cache[which], c->npix) != hipSuccess) { (void)hipGetLastError(); c->d_prim_cache[which] = nullptr; }
             prim = c->d_prim_cache[which];
         }
-        const int blocks = lone ? c->render_blocks : (c->render_blocks / c->grid_div + 7) & ~7;  // whole rounds of the 8 XCDs
-        if (c->pooled) HIP_TRY(launch_render_pool(rs, c->cfg.grid_res, restir, instr, blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch[lane_of - 1] : c->d_pool_scratch, c->drain_signal, prim, culling(c), c->dense_grid));
+        const bool d12 = c->pooled && c->render_blocks_d12 > 0 && pool_uses_dense12(c->cfg.grid_res, restir, c->dense_grid, fp);
+        const int all_blocks = d12 ? c->render_blocks_d12 : c->render_blocks;
+        const int blocks = lone ? all_blocks : (all_blocks / c->grid_div + 7) & ~7;  // whole rounds of the 8 XCDs
+        if (c->pooled) HIP_TRY(launch_render_pool(rs, c->cfg.grid_res, restir, instr, blocks, fp, sc, out, c->d_work, seq, g, (overlapped && lane_of) ? c->alt_pool_scratch[lane_of - 1] : c->d_pool_scratch, c->drain_signal, prim, culling(c), c->dense_grid, d12));
         else HIP_TRY(launch_render(rs, c->cfg.grid_res, restir, instr, c->render_blocks, fp, sc, out, c->d_work, seq, g, c->knobs.chunk));
         c->drain_signalled = c->pooled && c->drain_signal != nullptr;
-        c->prev_launch_full = blocks == c->render_blocks;
+        c->prev_launch_full = blocks == all_blocks;
         if (c->prev_launch_full && c->pooled) c->last_full_seq = seq + 1u;
         HIP_TRY(hipEventRecord(b, rs));
         if (overlapped) {

@@ -43,13 +43,16 @@ hipError_t launch_render(hipStream_t st, int grid_res, bool restir, bool instr, 
 // pooled schedule (vrt_pool.h).  `cold` holds pool_scratch_bytes(grid_res, restir, n_blocks) bytes.
 hipError_t query_render_pool_residency(int grid_res, bool restir, bool instr, int* blocks_per_cu);
 int pool_waves_per_block(int grid_res);
-size_t pool_scratch_bytes(int grid_res, bool restir, int n_blocks);
+size_t pool_scratch_bytes(int grid_res, bool restir, int n_blocks, int n_blocks_dense12);
+hipError_t query_render_pool_dense12_residency(bool instr, int* blocks_per_cu);
+bool pool_uses_dense12(int grid_res, bool restir, bool dense, const FrameParams& fp);
 hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                               const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold,
                               uint32_t* drain_signal,   // signal memory (or null): receives launch_seq + 1 when the launch starts to drain
                               PrimaryRecord* prim_cache,        // per-pixel camera-ray records shared by the fused samples (or null), npix entries
                               bool cull,                        // the instantiation that tests rays against sc.cull (cull_ray, vrt_trace.h)
-                              bool dense);                      // ... whose SHADE walks its shadow rays with the branchy descent (dense grids)
+                              bool dense,                       // ... whose SHADE walks its shadow rays with the branchy descent (dense grids)
+                              bool dense12);                    // ... on the twelve-wave geometry (pool_uses_dense12; n_blocks counts ITS workgroups)
 hipError_t launch_mat_derived(hipStream_t st, const float* mats, float* mats_x /*[128][8]*/);  // after every material upload
 // spatial reuse over rows [r0, r1); first a per-pixel prepare pass over all rows the launch holds (fp.row0..fp.row1) into gb.geo / gb.src
 hipError_t launch_gris(hipStream_t st, int grid_res, bool instr, const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, int r0, int r1);

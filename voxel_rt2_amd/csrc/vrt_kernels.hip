@@ -326,7 +326,7 @@ __global__ __launch_bounds__(VRT_RENDER_THREADS, VRT_RENDER_MIN_WAVES) void k_re
 #ifndef VRT_POOL_FINE_WORDS
 #define VRT_POOL_FINE_WORDS 1024   // fine brick words of the scene kept in LDS (8 KB): all of a sparse scene's
 #endif
-#define VRT_POOL_WORDS ((VRT_POOL_SLOTS + 63) / 64)   // state words per lane; slots past VRT_POOL_SLOTS are void (state 4)
+// (state words per lane = (SLOTS + 63) / 64; slots past SLOTS are void: state 4)
 
 __device__ __forceinline__ void wave_lds_sync() {  // LDS written by some lanes of this wave, read by others
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -337,7 +337,10 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-template <int G, bool RESTIR, bool INSTR, bool BLACK_SUN, bool CULL, bool SHBR = false>
+// WAVES path pools of SLOTS slots per workgroup: 4 x 128 with two workgroups per CU (two waves per SIMD) by default; the whole l1
+// level of a 256^3 grid leaves room for one workgroup of 8 x 128 per CU; a DENSE 128^3 grid runs one workgroup of 12 x 96 per CU
+// -- three waves per SIMD at 168 registers (k_render_pool_dense12 below).
+template <int G, bool RESTIR, bool INSTR, bool BLACK_SUN, bool CULL, bool SHBR = false, int WAVES = PoolGeom<G>::waves, int SLOTS = VRT_POOL_SLOTS>
 // 208 registers per wave (the attribute counts half of the unified file): two waves per SIMD then leave the 96 that
 // k_temporal runs in beside them (see there).  The allocator would take 238; the cap costs 28 bytes of scratch.
 // The ReSTIR instantiation (no overlapped launches, so nothing runs beside it) takes the two-wave maximum of 256.
@@ -345,7 +348,7 @@ template <int G, bool RESTIR, bool INSTR, bool BLACK_SUN, bool CULL, bool SHBR =
 #define VRT_POOL_HALF_VGPRS 104
 #endif
 __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const SceneData& sc, const PixelBuffers& out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
-    constexpr int WAVES = PoolGeom<G>::waves;
+    constexpr int WORDS = (SLOTS + 63) / 64;
     constexpr bool BIG = (G == 256);   // which coarse levels are staged how: see LdsPyramid2
     __shared__ ulonglong2 s_l12[BIG ? 1 : 512];
     __shared__ unsigned long long s_l1[BIG ? 4096 : 1];
@@ -354,9 +357,9 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
     __shared__ uint32_t s_fine_base[BIG ? 1 : 512];
     __shared__ float s_mats[128 * 14];
     __shared__ float s_cull[8];
-    __shared__ uint32_t s_pool[WAVES][PF_COUNT * VRT_POOL_SLOTS];
-    __shared__ uint32_t s_state[WAVES][VRT_POOL_WORDS * 64];
-    __shared__ uint32_t s_list[WAVES][VRT_POOL_SLOTS];
+    __shared__ uint32_t s_pool[WAVES][PF_COUNT * SLOTS];
+    __shared__ uint32_t s_state[WAVES][WORDS * 64];
+    __shared__ uint32_t s_list[WAVES][SLOTS];
     LdsPyramid2<G, CULL, SHBR, INSTR> P;
     P.l0 = sc.pyr.l0; P.l2 = s_l2;
     P.oob = sc.pyr.ref_oob != 0;
@@ -387,13 +390,13 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
     uint32_t* const pool = s_pool[wave];
     uint32_t* const state = s_state[wave];
     uint32_t* const list = s_list[wave];
-    for (int k = 0; k < VRT_POOL_WORDS; k++) state[k * 64 + lane] = (k * 64 + lane < VRT_POOL_SLOTS) ? (uint32_t)SLOT_EMPTY : 4u;
+    for (int k = 0; k < WORDS; k++) state[k * 64 + lane] = (k * 64 + lane < SLOTS) ? (uint32_t)SLOT_EMPTY : 4u;
     __syncthreads();
     SceneData scl = sc;
     scl.mats = s_mats;
     scl.cull = s_cull;
     constexpr int COLD = ColdLine<RESTIR>::count;
-    uint32_t* const cold_wave = cold + (size_t)(blockIdx.x * WAVES + wave) * VRT_POOL_SLOTS * COLD;
+    uint32_t* const cold_wave = cold + (size_t)(blockIdx.x * WAVES + wave) * SLOTS * COLD;
 
     const int tiles_x = (fp.W + 7) >> 3;
     const int tiles_y = (fp.row1 - fp.row0 + 7) >> 3;
@@ -435,10 +438,10 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
         wave_lds_sync();
         VRT_POOL_CLOCK(5);  // 5 = census + list
         // census
-        uint32_t st[VRT_POOL_WORDS];
+        uint32_t st[WORDS];
         int cnt[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < VRT_POOL_WORDS; k++) {
+        for (int k = 0; k < WORDS; k++) {
             st[k] = state[k * 64 + lane];
 #pragma unroll
             for (int q = 0; q < 4; q++) cnt[q] += __popcll(__ballot(st[k] == (uint32_t)q));
@@ -454,7 +457,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
         // compacted list of that stage's slots
         int n = 0;
 #pragma unroll
-        for (int k = 0; k < VRT_POOL_WORDS; k++) {
+        for (int k = 0; k < WORDS; k++) {
             const bool mine = st[k] == (uint32_t)stage;
             const unsigned long long m = __ballot(mine);
             if (mine) list[n + lane_rank(m)] = (uint32_t)(k * 64 + lane);
@@ -477,7 +480,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
             CoarseWords cw;
             cw.w1 = 0ULL; cw.w2 = 0ULL;
             SlotRef s;
-            s.base = pool; s.stride = VRT_POOL_SLOTS;
+            s.base = pool; s.stride = SLOTS;
             int slot = 0, iters0 = 0;
             for (;;) {
                 // event: finished walks go to their slots, idle lanes take the next pending rays -- or, with the
@@ -561,7 +564,7 @@ __device__ __forceinline__ void render_pool_body(const FrameParams& fp, const Sc
             }
             if (lane < take) {
                 SlotRef s;
-                s.stride = VRT_POOL_SLOTS;
+                s.stride = SLOTS;
                 if (stage == SLOT_SHADE) {
                     VRT_REGION(11);
                     const int slot = (int)list[lane];
@@ -628,6 +631,17 @@ template <int G, bool INSTR, bool CULL>
 __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(VRT_POOL_HALF_VGPRS))) void k_render_pool_dense(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
     render_pool_body<G, false, INSTR, false, CULL, true>(fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, drain_value, prim_cache);
 }
+// ... and at 128^3 the same with THREE waves per SIMD: one workgroup of twelve waves per CU, 96 slots per pool (12 x 10.4 KB of pools
+// + 25 KB of pyramid and materials = 148 KB of LDS), 168 registers (21-36 spilled).  A dense grid's rays end after a step or two, so
+// its waves spend their time in SHADE waiting on texel and shadow-ray loads, which a third wave covers: the dense 4K frame
+// 2 673 -> 2 953 Mpath-samples/s.  A sparse scene loses as much with it (config 2 -3.6 %, sun-lit -6 %: fewer slots per pool
+// thin the WALK stage out, and the spills cost), so only launches the dense variant would take anyway use it.
+#define VRT_D12_WAVES 12
+#define VRT_D12_SLOTS 96
+template <bool INSTR, bool CULL>
+__global__ __launch_bounds__(64 * VRT_D12_WAVES, 3) __attribute__((amdgpu_num_vgpr(84))) void k_render_pool_dense12(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
+    render_pool_body<128, false, INSTR, false, CULL, true, VRT_D12_WAVES, VRT_D12_SLOTS>(fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, drain_value, prim_cache);
+}
 template <int G, bool INSTR, bool CULL>
 __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(128))) void k_render_pool_restir(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
     render_pool_body<G, true, INSTR, false, CULL>(fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, drain_value, prim_cache);
@@ -688,6 +702,103 @@ __global__ __launch_bounds__(256, (PHASE == 1 ? VRT_GRIS_MIN_WAVES_A : PHASE == 
     TraceStats ts;
     stats_zero(ts);
     if (bx < tiles_x && u < fp.W && v >= r_first && v < r1) gris_pixel<PHASE>(fp, scl, P, gbl, taps, u, v, 0, 24.0f, 32, 1, ts);
+    if (INSTR) flush_stats(ts, sc.counters);
+}
+
+// The first kernel of the split pass (pathtracer.py:917-931: the centre's sample shifted into every accepted neighbour's domain; the
+// sum of the terms is the canonical MIS weight), on a WAVE-LEVEL schedule.  Whether a pixel's shifts need evaluating is a
+// property of ITS sample (gris_classify_pixel: a dead sample makes every one of them a constant), so the counts are bimodal
+// -- 0 or ~25 taps per pixel, 7.8 on average in a scene open to the sky -- and a loop per lane runs as long as the wave's busiest
+// pixel (measured: 16.6 trips at 30 of 64 lanes).  Here the wave's 8x8 pixels pool their taps: every lane lists its live taps in
+// LDS, the wave evaluates the list 64 at a time (a lane loads the sample of whichever pixel its item belongs to: 224 bytes from
+// L2 instead of registers kept across a loop) and leaves each term where the item was; then every lane sums ITS pixel's terms in
+// tap order, constants included -- the float sum of gris_pixel<1>, term for term (gris_first_term is the loop's body).
+template <int G, bool INSTR>
+__global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES_A) void k_gris_first(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r_first, int r1, int tiles_x, int band_w) {
+    __shared__ float s_mats[128 * 14];
+    __shared__ float s_mats_x[128 * 8];
+    __shared__ float s_cs[4][64];          // per wave (= 8x8 pixel tile): cos / sin of the 32 tap angles
+    __shared__ uint32_t s_item[4][64 * 32];  // per wave: (lane << 8 | tap) of every tap to evaluate, then the tap's term in its place
+    __shared__ float s_radius[4][64];      // per wave: each pixel's radius_shift
+    for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
+    for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) s_mats_x[i] = gb.mats_x[i];
+    SceneData scl = sc;
+    scl.mats = s_mats;
+    GrisBuffers gbl = gb;
+    gbl.mats_x = s_mats_x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bx = xcd * band_w + slot % band_w, by = slot / band_w;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int u0 = bx * 16 + (wave & 1) * 8, v0 = r0 + by * 16 + (wave >> 1) * 8;   // the wave's 8x8 tile (one tile of the tap-angle hash)
+    const int u = u0 + (lane & 7), v = v0 + (lane >> 3);
+    if (lane < 32) gris_tap_cs(u, v, 0, lane, s_cs[wave]);
+    __syncthreads();
+    GrisTaps taps;
+    taps.cs = s_cs[wave]; taps.off = nullptr; taps.off_stride = 0;
+    TraceStats ts;
+    stats_zero(ts);
+    const int max_taps = 32;
+    const float max_radius = 24.0f;
+    uint32_t* const item = s_item[wave];
+
+    // this lane's own pixel: gris_pixel<1>'s early outs, its masks and the constant term
+    const int idx = (v - fp.row0) * fp.W + u;
+    bool mine = bx < tiles_x && u < fp.W && v >= r_first && v < r1 && !outside_render_area(fp, (float)u, (float)v);
+    unsigned accepted = 0u, walk = 0u;
+    float const_term = 0.0f;
+    if (mine) {
+        const GrisGeo* cg = &gb.geo[idx];
+        if (near_zero3(cg->x1)) mine = false;
+        else {
+            dm_rng rng = dm_rng_init(fp.seed, fp.frame, (uint32_t)(v * fp.W + u), 1u);
+            (void)dm_rng_f32(&rng);  // start_index draw (:827), value unused
+            s_radius[wave][lane] = dm_rng_f32(&rng);
+            accepted = cg->pad;
+            walk = accepted & gb.src[idx].pad2;
+            Reservoir c;
+            c.z.F = gb.src[idx].F; c.M = gb.src[idx].M;
+            const_term = gris_first_const_term(c, max_taps);
+        }
+    }
+    // where this lane's items start in the wave's list: exclusive prefix sum of the counts
+    const int cnt = __builtin_popcount(walk);
+    int incl = cnt;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    const int base = incl - cnt;
+    const int total = __shfl(incl, 63, 64);
+    {
+        int k = base;
+        for (unsigned m = walk; m != 0u; m &= m - 1u) item[k++] = ((uint32_t)lane << 8) | (uint32_t)__builtin_ctz(m);
+    }
+    wave_lds_sync();
+    for (int k0 = 0; k0 < total; k0 += 64) {
+        const int k = k0 + lane;
+        if (k < total) {
+            const uint32_t e = item[k];
+            const int q = (int)(e >> 8), i = (int)(e & 31u);
+            const int uq = u0 + (q & 7), vq = v0 + (q >> 3);
+            int tx, ty;
+            (void)gris_tap(fp, taps, uq, vq, i, s_radius[wave][q], max_radius, max_taps, tx, ty);
+            Reservoir center;
+            f3 center_rc_ty, center_sky_t;
+            RcPre center_pre;
+            gris_load_src(center, center_rc_ty, center_sky_t, center_pre, gb.src[(vq - fp.row0) * fp.W + uq]);
+            item[k] = dm_f2u(gris_first_term(fp, scl, gbl, center, center_rc_ty, center_sky_t, center_pre, tx, ty, max_taps, ts));
+        }
+    }
+    wave_lds_sync();
+    if (mine) {
+        float canonical_mis = 1.0f;
+        int k = base;
+        for (unsigned m = accepted; m != 0u; m &= m - 1u) {
+            const int i = __builtin_ctz(m);
+            canonical_mis += ((walk >> i) & 1u) ? dm_u2f(item[k++]) : const_term;
+        }
+        gb.geo[idx].pad3 = dm_f2u(canonical_mis);
+    }
     if (INSTR) flush_stats(ts, sc.counters);
 }
 
@@ -849,21 +960,29 @@ hipError_t launch_render(hipStream_t st, int grid_res, bool restir, bool instr, 
     return hipSuccess;
 }
 int pool_waves_per_block(int grid_res) { return grid_res == 256 ? PoolGeom<256>::waves : PoolGeom<128>::waves; }
+hipError_t query_render_pool_dense12_residency(bool instr, int* blocks_per_cu) {
+    hipError_t e = hipSuccess;
+    VRT_BY_2(instr, false, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool_dense12<A, true>, 64 * VRT_D12_WAVES, 0));
+    return e;
+}
 hipError_t query_render_pool_residency(int grid_res, bool restir, bool instr, int* blocks_per_cu) {
     hipError_t e = hipSuccess;
     if (restir) VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool_restir<G, A, true>, 64 * PoolGeom<G>::waves, 0)));
     else VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool<G, A, B, true>, 64 * PoolGeom<G>::waves, 0)));
     return e;
 }
-size_t pool_scratch_bytes(int grid_res, bool restir, int n_blocks) {
-    return (size_t)n_blocks * pool_waves_per_block(grid_res) * VRT_POOL_SLOTS * (restir ? ColdLine<true>::count : ColdLine<false>::count) * sizeof(uint32_t);
+size_t pool_scratch_bytes(int grid_res, bool restir, int n_blocks, int n_blocks_dense12) {   // room for either geometry
+    const size_t line = (size_t)(restir ? ColdLine<true>::count : ColdLine<false>::count) * sizeof(uint32_t);
+    const size_t a = (size_t)n_blocks * pool_waves_per_block(grid_res) * VRT_POOL_SLOTS * line;
+    const size_t b = (size_t)n_blocks_dense12 * VRT_D12_WAVES * VRT_D12_SLOTS * line;
+    return a > b ? a : b;
 }
 hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                               const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold,
-                              uint32_t* drain_signal, PrimaryRecord* prim_cache, bool cull, bool dense) {
+                              uint32_t* drain_signal, PrimaryRecord* prim_cache, bool cull, bool dense, bool dense12) {
     unsigned* work_counter = work_counters + (launch_seq & 15u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
     unsigned* next_counter = work_counters + ((launch_seq + 8u) & 15u) * (VRT_WORK_HEADS * VRT_WORK_HEAD_STRIDE);
-    dim3 g(n_blocks), b(64 * pool_waves_per_block(grid_res));
+    dim3 g(n_blocks), b(64 * (dense12 ? VRT_D12_WAVES : pool_waves_per_block(grid_res)));
     // the signal carries launch_seq + 1 of the latest launch that has begun to drain
     // the black-sun variant (scene.py's default light) compiles the light sample out of the shading stage
     const bool black_sun = !((fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f);
@@ -871,6 +990,8 @@ hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool in
     if (restir) {  // the reservoir needs the light sample whatever the sun's colour
         if (cull) VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_render_pool_restir<G, A, true>), VRT_POOL_ARGS)));
         else VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_render_pool_restir<G, A, false>), VRT_POOL_ARGS)));
+    } else if (dense12) {               // (the caller's choice: pool_uses_dense12)
+        VRT_BY_2(instr, cull, hipLaunchKernelGGL((k_render_pool_dense12<A, B>), VRT_POOL_ARGS));
     } else if (dense && !black_sun) {   // (with a black sun SHADE walks next to no shadow rays)
         VRT_BY_GRID(grid_res, VRT_BY_2(instr, cull, hipLaunchKernelGGL((k_render_pool_dense<G, A, B>), VRT_POOL_ARGS)));
     } else {
@@ -880,6 +1001,11 @@ hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool in
 #undef VRT_POOL_ARGS
     VRT_LAUNCH_CHECK();
     return hipSuccess;
+}
+// the launches that take the twelve-wave geometry: the ones the dense variant takes at 128^3
+bool pool_uses_dense12(int grid_res, bool restir, bool dense, const FrameParams& fp) {
+    const bool black_sun = !((fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f);
+    return grid_res == 128 && !restir && dense && !black_sun;
 }
 hipError_t launch_mat_derived(hipStream_t st, const float* mats, float* mats_x) {
     hipLaunchKernelGGL(k_mat_derived, dim3(1), dim3(128), 0, st, mats, mats_x);
@@ -896,7 +1022,7 @@ hipError_t launch_gris(hipStream_t st, int grid_res, bool instr, const FramePara
 #if VRT_GRIS_SPLIT
     if (instr) hipLaunchKernelGGL((k_gris_classify<true>), g, b, 0, st, fp, sc, gb, ra, r0, r1, tiles_x, band_w);
     else hipLaunchKernelGGL((k_gris_classify<false>), g, b, 0, st, fp, sc, gb, ra, r0, r1, tiles_x, band_w);
-    VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_gris<G, A, 1>), g, b, 0, st, fp, sc, gb, ra, r0, r1, tiles_x, band_w)));
+    VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_gris_first<G, A>), g, b, 0, st, fp, sc, gb, ra, r0, r1, tiles_x, band_w)));
     VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_gris<G, A, 2>), g, b, 0, st, fp, sc, gb, ra, r0, r1, tiles_x, band_w)));
 #else
     VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_gris<G, A>), g, b, 0, st, fp, sc, gb, ra, r0, r1, tiles_x, band_w)));

@@ -210,7 +210,8 @@ VRT_DEV bool shift_is_constant(f3 dst_pos, f3 dst_normal, bool dst_ok, float dst
     return !(nl > 0.0f) || (nl >= 1e-5f && dst_ok);
 }
 VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const float* mats_x, f3 dst_pos, const Surf& ds, const SurfShared& dsc,
-                          const Reservoir& src, f3 rc_ty, f3 src_sky_t, const RcPre& pre, f3& out_d, f3& out_s, float& out_jac, TraceStats& ts) {
+                          const Reservoir& src, f3 rc_ty, f3 src_sky_t, const RcPre& pre, f3& out_d, f3& out_s, float& out_jac, TraceStats& ts,
+                          int dg = 0 /* first diagnostic region of the caller (VRT_GREGION; nothing in the shipped library) */) {
     const bool escape = near_zero3(src.z.rc_normal);
     const bool last = near_zero3(src.z.rc_incident_dir);
     const bool nee_vis = !near_zero3(src.z.rc_nee_dir);
@@ -224,6 +225,7 @@ VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const floa
     rc_mat.base = pre.base;
     f3 contrib = mk3(0.0f);
     if (!escape) {
+        VRT_GREGION(dg + 1);
         Surf rc;
         surf_set(rc, rc_mat, load_mat_derived(mats_x, rc_id), src.z.rc_normal, -to_rc, cross3(src.z.rc_normal, rc_ty), rc_ty);
         // two directions (the path's continuation and its sun sample) with their pdfs at one vertex: bsdf_eval_pdf
@@ -231,6 +233,7 @@ VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const floa
         const SurfShared rcc = surf_shared_view(rc, pre.col, nee_vis || (!last && lobe_has(rl, LOBE_DIFFUSE)), nee_vis || (!last && lobe_has(rl, LOBE_SPEC)),
                                                 nee_vis || (!last && lobe_has(rl, LOBE_CLEARCOAT)));
         if (!last) {
+            VRT_GREGION(dg + 2);
             f3 bd, bs;
             float dst_rc_pdf;
             bsdf_eval_pdf_pre(rc, rcc, src.z.rc_incident_dir, pre.inc, rl, PDF_LOBE, bd, bs, dst_rc_pdf);
@@ -240,6 +243,7 @@ VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const floa
             contrib = contrib + firefly(w * rc_brdf / dst_rc_pdf * src.z.rc_incident_L);
         }
         if (nee_vis) {
+            VRT_GREGION(dg + 3);
             f3 bd, bs;
             float pdf_nee;
             bsdf_eval_pdf_pre(rc, rcc, src.z.rc_nee_dir, pre.nee, LOBE_ALL, PDF_ALL, bd, bs, pdf_nee);
@@ -256,6 +260,11 @@ VRT_DEV void shift_sample(const FrameParams& fp, const SceneData& sc, const floa
 
     f3 pd, ps;
     float no_pdf;
+    if (dot3(ds.n, to_rc) > 0.0f && ds.n_v > 0.0f) {
+        VRT_GREGION(dg + 4);                                            // (diagnostic only: the destination's BSDF is not an exact zero ...
+        if (lobe_has(src.z.lobes % 10, LOBE_DIFFUSE)) { VRT_GREGION(dg + 5); }   // ... and which of its lobes are evaluated)
+        if (lobe_has(src.z.lobes % 10, LOBE_SPEC)) { VRT_GREGION(dg + 6); }
+    }
     bsdf_eval_pdf(ds, dsc, to_rc, src.z.lobes % 10, PDF_NONE, pd, ps, no_pdf);
     const float c = dm_saturate(dot3(dst_normal, to_rc));
     pd = pd * c;
@@ -495,6 +504,36 @@ VRT_DEV void gris_classify_pixel(const FrameParams& fp, const GrisBuffers& gb, c
     gb.src[idx].pad2 = live_first;
 }
 
+// One trip of the first tap loop (:917-931): the CENTRE's sample shifted into the domain of the neighbour at pixel (tx, ty); returns its
+// term 1 - cw of the canonical MIS weight.  Shared by the per-pixel loop below and by the first kernel's wave-level schedule
+// (k_gris<., ., 1>, vrt_kernels.hip), where a lane works on whichever pixel's tap it is dealt.
+VRT_DEV float gris_first_term(const FrameParams& fp, const SceneData& sc, const GrisBuffers& gb, const Reservoir& center, f3 center_rc_ty,
+                              f3 center_sky_t, const RcPre& center_pre, int tx, int ty, int max_taps, TraceStats& ts) {
+    const GrisGeo ng = gb.geo[(ty - fp.row0) * fp.W + tx];
+    const float nb_M = ng.M;
+    const int nmat_id = (int)(ng.mat & 255u);
+    Material nmat = load_material(sc.mats, nmat_id);
+    nmat.base = ng.base;
+    f3 cd, cs;
+    float cjac;
+    Surf nds;
+    surf_set(nds, nmat, load_mat_derived(gb.mats_x, nmat_id), ng.n, ng.v, cross3(ng.n, ng.ty), ng.ty);
+    SurfShared ndsc;   // the neighbour's own shading point: all of it from the prepare pass
+    ndsc.lambert = ng.lambert; ndsc.sheen_col = ng.sheen_col; ndsc.spec_col = ng.spec_col; ndsc.fv = ng.fv; ndsc.g_v = ng.g_v; ndsc.gc_v = ng.gc_v;
+    VRT_GREGION(0);
+    shift_sample(fp, sc, gb.mats_x, ng.x1, nds, ndsc, center, center_rc_ty, center_sky_t, center_pre, cd, cs, cjac, ts, 0);
+    float c_p_hat = lum(cd + cs) * cjac;
+    float cw = c_p_hat * nb_M;
+    cw /= c_p_hat * nb_M + lum(center.z.F) * center.M / (float)max_taps;
+    return 1.0f - cw;
+}
+// The term of a tap whose centre -> neighbour shift is a known constant (shift_is_constant): c_p_hat = L * 0.
+VRT_DEV float gris_first_const_term(const Reservoir& center, int max_taps) {
+    float cw = 0.0f;
+    cw /= 0.0f + lum(center.z.F) * center.M / (float)max_taps;
+    return 1.0f - cw;
+}
+
 // pathtracer.py:815-989, called as spatial_GRIS(0, 24.0, 32, 1) (:1313)
 // PHASE 0: the whole pass.  PHASE 1 / 2: the pass as two kernels behind gris_classify_pixel, which leaves them the mask of
 // accepted taps in the pixel's own GrisGeo record (pad) -- the canonical MIS weight (second loop), left in pad3 (nobody else reads
@@ -569,9 +608,7 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     if (PHASE == 1) {
         walk = accepted & gb.src[idx].pad2;
         pending = accepted;
-        float cw = 0.0f;                                            // c_p_hat * nb_M with c_p_hat = L * 0
-        cw /= 0.0f + lum(center.z.F) * center.M / (float)max_taps;
-        const_term = 1.0f - cw;
+        const_term = gris_first_const_term(center, max_taps);
     }
     for (unsigned m = walk; m != 0u; m &= m - 1u) {
         const int i = __builtin_ctz(m);
@@ -585,22 +622,7 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
             const int packed = taps.off[i * taps.off_stride];
             tx = u + (packed & 255) - 128; ty = v + (packed >> 8) - 128;
         }
-        const GrisGeo ng = gb.geo[(ty - fp.row0) * fp.W + tx];
-        const float nb_M = ng.M;
-        const int nmat_id = (int)(ng.mat & 255u);
-        Material nmat = load_material(sc.mats, nmat_id);
-        nmat.base = ng.base;
-        f3 cd, cs;
-        float cjac;
-        Surf nds;
-        surf_set(nds, nmat, load_mat_derived(gb.mats_x, nmat_id), ng.n, ng.v, cross3(ng.n, ng.ty), ng.ty);
-        SurfShared ndsc;   // the neighbour's own shading point: all of it from the prepare pass
-        ndsc.lambert = ng.lambert; ndsc.sheen_col = ng.sheen_col; ndsc.spec_col = ng.spec_col; ndsc.fv = ng.fv; ndsc.g_v = ng.g_v; ndsc.gc_v = ng.gc_v;
-        shift_sample(fp, sc, gb.mats_x, ng.x1, nds, ndsc, center, center_rc_ty, center_sky_t, center_pre, cd, cs, cjac, ts);
-        float c_p_hat = lum(cd + cs) * cjac;
-        float cw = c_p_hat * nb_M;
-        cw /= c_p_hat * nb_M + lum(center.z.F) * center.M / (float)max_taps;
-        canonical_mis += 1.0f - cw;
+        canonical_mis += gris_first_term(fp, sc, gb, center, center_rc_ty, center_sky_t, center_pre, tx, ty, max_taps, ts);
     }
     // Register budget (the kernel is held to 256 and waits on spill reloads): the first tap loop carries the centre's sample,
     // the second the centre's shading point and the output reservoir -- neither needs the other's, so the shading point is
@@ -666,7 +688,8 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
         gris_load_src(nb, nb_rc_ty, nb_sky_t, nb_pre, gb.src[(ty - fp.row0) * fp.W + tx]);
         f3 sd, ss;
         float jac;
-        shift_sample(fp, sc, gb.mats_x, cx1, cds, cdsc, nb, nb_rc_ty, nb_sky_t, nb_pre, sd, ss, jac, ts);
+        VRT_GREGION(8);
+        shift_sample(fp, sc, gb.mats_x, cx1, cds, cdsc, nb, nb_rc_ty, nb_sky_t, nb_pre, sd, ss, jac, ts, 8);
 
         float p_hat = lum(sd + ss);
         float p_hat_n = p_hat / jac;
@@ -713,6 +736,7 @@ VRT_DEV void gris_pixel(const FrameParams& fp, const SceneData& sc, const PyrT& 
     // so that ray's result cannot be observed -- and an EMPTY output reservoir (rc_pos = 0) would make it a
     // zero-direction ray that spins the DDA for all 512 iterations.  Only the reconnection case is traced.
     if (!out_escape) {
+        VRT_GREGION(15);
         const f3 to_rc = norm3(outr.z.rc_pos - cx1);
         Hit sh;
         next_hit<true>(fp, sc, P, cx1 + cn1 * 0.003f * cdist, to_rc, sh, ts);

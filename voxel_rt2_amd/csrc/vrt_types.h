@@ -88,7 +88,7 @@ VRT_DEV f4 mul4(const mat4& M, f4 v) {
 #if defined(VRT_DIAG_REGIONS) && defined(__HIPCC__)
 static __device__ unsigned long long g_vrt_region[64];
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(VRT_DIAG_CLOCKS_ONLY)  // CLOCKS_ONLY: just the pooled kernel's stage clocks
-#define VRT_REGION(id)                                                                                             \
+#define VRT_REGION_COUNT(id)                                                                                        \
     do {                                                                                                            \
         unsigned long long m_ = __ballot(1);                                                                        \
         if ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (int)__ffsll((long long)m_) - 1) { \
@@ -97,10 +97,19 @@ static __device__ unsigned long long g_vrt_region[64];
         }                                                                                                           \
     } while (0)
 #else
-#define VRT_REGION(id) ((void)0)
+#define VRT_REGION_COUNT(id) ((void)0)
 #endif
 #else
+#define VRT_REGION_COUNT(id) ((void)0)
+#endif
+// -DVRT_DIAG_GRIS (with -DVRT_DIAG_REGIONS): the same 32 counters count the regions of the spatial-reuse kernels instead
+// (VRT_GREGION, vrt_restir.h; tools/diag_regions.py gris)
+#if defined(VRT_DIAG_GRIS)
 #define VRT_REGION(id) ((void)0)
+#define VRT_GREGION(id) VRT_REGION_COUNT(id)
+#else
+#define VRT_REGION(id) VRT_REGION_COUNT(id)
+#define VRT_GREGION(id) ((void)0)
 #endif
 
 // The voxel grid is G^3 cells, G = 128 (the reference's voxel_grid_res, pathtracer.py:83) or 256 (BASELINE config 5:
