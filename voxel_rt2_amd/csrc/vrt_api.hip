@@ -778,9 +778,9 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         if (cus < 8) cus = c->n_cu < 8 ? c->n_cu : 8;
         c->render_blocks = per_cu * cus;   // (abort_pipeline zeroes it again if an allocation below fails)
         c->render_blocks_d12 = 0;
-        if (pooled && !restir && c->cfg.grid_res == 128) {
+        if (pooled && !restir) {
             int per_cu12 = 0;
-            HIP_TRY(query_render_pool_dense12_residency(instr, &per_cu12));
+            HIP_TRY(query_render_pool_dense12_residency(c->cfg.grid_res, instr, &per_cu12));
             c->render_blocks_d12 = (per_cu12 < 1 ? 1 : per_cu12) * cus;
         }
         c->pooled = pooled;

@@ -44,7 +44,7 @@ hipError_t launch_render(hipStream_t st, int grid_res, bool restir, bool instr, 
 hipError_t query_render_pool_residency(int grid_res, bool restir, bool instr, int* blocks_per_cu);
 int pool_waves_per_block(int grid_res);
 size_t pool_scratch_bytes(int grid_res, bool restir, int n_blocks, int n_blocks_dense12);
-hipError_t query_render_pool_dense12_residency(bool instr, int* blocks_per_cu);
+hipError_t query_render_pool_dense12_residency(int grid_res, bool instr, int* blocks_per_cu);
 bool pool_uses_dense12(int grid_res, bool restir, bool dense, const FrameParams& fp);
 hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool instr, int n_blocks, const FrameParams& fp, const SceneData& sc,
                               const PixelBuffers& out, unsigned* work_counters, unsigned launch_seq, int n_samples, uint32_t* cold,

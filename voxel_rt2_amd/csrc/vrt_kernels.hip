@@ -636,11 +636,16 @@ __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attr
 // its waves spend their time in SHADE waiting on texel and shadow-ray loads, which a third wave covers: the dense 4K frame
 // 2 673 -> 2 953 Mpath-samples/s.  A sparse scene loses as much with it (config 2 -3.6 %, sun-lit -6 %: fewer slots per pool
 // thin the WALK stage out, and the spills cost), so only launches the dense variant would take anyway use it.
+// At 256^3 the staged l1 level (32 KB) leaves the twelve pools 88 slots each (153 KB of LDS in all).
 #define VRT_D12_WAVES 12
 #define VRT_D12_SLOTS 96
-template <bool INSTR, bool CULL>
+#ifndef VRT_D12_SLOTS_256
+#define VRT_D12_SLOTS_256 88
+#endif
+template <int G> struct D12Slots { static constexpr int value = G == 256 ? VRT_D12_SLOTS_256 : VRT_D12_SLOTS; };
+template <int G, bool INSTR, bool CULL>
 __global__ __launch_bounds__(64 * VRT_D12_WAVES, 3) __attribute__((amdgpu_num_vgpr(84))) void k_render_pool_dense12(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
-    render_pool_body<128, false, INSTR, false, CULL, true, VRT_D12_WAVES, VRT_D12_SLOTS>(fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, drain_value, prim_cache);
+    render_pool_body<G, false, INSTR, false, CULL, true, VRT_D12_WAVES, D12Slots<G>::value>(fp, sc, out, work_counter, next_counter, n_samples, cold, drain_signal, drain_value, prim_cache);
 }
 template <int G, bool INSTR, bool CULL>
 __global__ __launch_bounds__(64 * PoolGeom<G>::waves, VRT_POOL_MIN_WAVES) __attribute__((amdgpu_num_vgpr(128))) void k_render_pool_restir(FrameParams fp, SceneData sc, PixelBuffers out, unsigned* work_counter, unsigned* next_counter, int n_samples, uint32_t* cold, uint32_t* drain_signal, uint32_t drain_value, PrimaryRecord* prim_cache) {
@@ -960,9 +965,9 @@ hipError_t launch_render(hipStream_t st, int grid_res, bool restir, bool instr, 
     return hipSuccess;
 }
 int pool_waves_per_block(int grid_res) { return grid_res == 256 ? PoolGeom<256>::waves : PoolGeom<128>::waves; }
-hipError_t query_render_pool_dense12_residency(bool instr, int* blocks_per_cu) {
+hipError_t query_render_pool_dense12_residency(int grid_res, bool instr, int* blocks_per_cu) {
     hipError_t e = hipSuccess;
-    VRT_BY_2(instr, false, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool_dense12<A, true>, 64 * VRT_D12_WAVES, 0));
+    VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_render_pool_dense12<G, A, true>, 64 * VRT_D12_WAVES, 0)));
     return e;
 }
 hipError_t query_render_pool_residency(int grid_res, bool restir, bool instr, int* blocks_per_cu) {
@@ -991,7 +996,7 @@ hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool in
         if (cull) VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_render_pool_restir<G, A, true>), VRT_POOL_ARGS)));
         else VRT_BY_GRID(grid_res, VRT_BY_2(instr, false, hipLaunchKernelGGL((k_render_pool_restir<G, A, false>), VRT_POOL_ARGS)));
     } else if (dense12) {               // (the caller's choice: pool_uses_dense12)
-        VRT_BY_2(instr, cull, hipLaunchKernelGGL((k_render_pool_dense12<A, B>), VRT_POOL_ARGS));
+        VRT_BY_GRID(grid_res, VRT_BY_2(instr, cull, hipLaunchKernelGGL((k_render_pool_dense12<G, A, B>), VRT_POOL_ARGS)));
     } else if (dense && !black_sun) {   // (with a black sun SHADE walks next to no shadow rays)
         VRT_BY_GRID(grid_res, VRT_BY_2(instr, cull, hipLaunchKernelGGL((k_render_pool_dense<G, A, B>), VRT_POOL_ARGS)));
     } else {
@@ -1005,7 +1010,8 @@ hipError_t launch_render_pool(hipStream_t st, int grid_res, bool restir, bool in
 // the launches that take the twelve-wave geometry: the ones the dense variant takes at 128^3
 bool pool_uses_dense12(int grid_res, bool restir, bool dense, const FrameParams& fp) {
     const bool black_sun = !((fp.light_color.x != 0.0f || fp.light_color.y != 0.0f || fp.light_color.z != 0.0f) && fp.light_weight != 0.0f);
-    return grid_res == 128 && !restir && dense && !black_sun;
+    (void)grid_res;
+    return !restir && dense && !black_sun;
 }
 hipError_t launch_mat_derived(hipStream_t st, const float* mats, float* mats_x) {
     hipLaunchKernelGGL(k_mat_derived, dim3(1), dim3(128), 0, st, mats, mats_x);
