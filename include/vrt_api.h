@@ -213,6 +213,15 @@ const char* vrt_build_id(void);
  * op 0 sin 1 cos 2 exp 3 log 4 pow 5 acos 6 atan2 7 min 8 max 9 f16 round trip 10 a/b 11 sqrt
  * 12 a*b+a (uncontracted) 13 float->int. */
 int vrt_detmath_probe(int device, int op, int n, const float* a, const float* b, float* out);
+/* Evaluate single functions of the sky / cloud precompute on the device (test hook; the rows the reference's own atmos.py was
+ * executed on: tests/golden/reference/functions_sky.npz).  op: 0 rsi (atmos.py:9-15) | 1 get_ozone_density (:500-518) | 2 get_density
+ * (:520-523) | 3 cloud_phase (:262-267) | 4 sample_cloud_density (:195-224) | 5 clouds_shadow_od (:231-260) | 6 get_ray_transmittance
+ * (:475-498) | 7 clouds_scattering (:269-349) | 8 / 9 atmospheric_scattering at template depth 0 / 1 (:355-425).  `in` holds n rows of
+ * in_stride floats: position, direction, then the function's other arguments (functions 7-9: sun direction, sun colour, cone cosine,
+ * dither or step count, index of the row's random stream); `out` n rows of out_stride floats.  trans_lut (f16[256][128][3]) and
+ * cloud_ambient (f32[3]), when not NULL, replace what vrt_prepare computed.  Needs sky_res > 0. */
+int vrt_sky_probe(vrt_ctx* ctx, int op, int n, const float* in, int in_stride, float* out, int out_stride, const uint16_t* trans_lut,
+                  const float* cloud_ambient);
 /* Diagnostic builds only (library compiled with -DVRT_DIAG_REGIONS, see tools/diag_regions.py): copy out the
  * 32 x {wave entries, active lanes} counters of the instrumented regions of the render kernel and optionally
  * zero them.  The shipped library returns VRT_E_STATE -- it carries no region counters. */

@@ -259,6 +259,49 @@ void orc_unit_unproject_sky(orc_ctx* c, const float* uv, float* out) {
     out[0] = d.x; out[1] = d.y; out[2] = d.z;
 }
 /* reservoir encode/decode round trip of one Sample given as 23 floats */
+/* ---- atmos.py, one function at a time (tests/golden/reference/functions.npz: sky_*) ----------------------------------------
+ * op: 0 rsi(pos, dir, r) -> 2 | 1 get_ozone_density(h) -> 1 | 2 get_density(h) -> 3 | 3 cloud_phase(cos, an) -> 1 |
+ *     4 sample_cloud_density(pos) -> 1 | 5 clouds_shadow_od(origin, dir, dither) -> 1 | 6 get_ray_transmittance(pos, dir) -> 3 |
+ *     7 clouds_scattering(origin, dir, sun_dir, sun_col, sun_cos, dither; stream index) -> scatter 3, transmittance, distance |
+ *     8 / 9 atmospheric_scattering at template depth 0 / 1 (origin, dir, sun_dir, sun_col, sun_cos, steps; stream index) -> scatter 3, transmittance 3
+ * `in` holds n rows of in_stride floats, `out` n rows of out_stride.  The functions that draw random numbers (7, 8, 9: the cone
+ * sampler) take them from stream 2 of (seed, frame 0x3000, the row's stream index).  orc_set_trans_lut / orc_set_cloud_ambient
+ * install what they read besides the cloud tile (orc_upload_cloud_texture). */
+int orc_set_trans_lut(orc_ctx* c, const uint16_t* lut) { memcpy(c->r.atmos.trans_LUT.data(), lut, 256 * 128 * 3 * sizeof(uint16_t)); return 0; }
+int orc_set_cloud_ambient(orc_ctx* c, const float* a) { c->r.atmos.cloud_ambient = v3(a[0], a[1], a[2]); return 0; }
+int orc_unit_atmos(orc_ctx* c, int op, int n, const float* in, int in_stride, float* out, int out_stride) {
+    const Atmos& A = c->r.atmos;
+    for (int k = 0; k < n; k++) {
+        const float* a = in + (size_t)k * in_stride;
+        float* o = out + (size_t)k * out_stride;
+        const V3 p = v3(a[0], a[1], a[2]), d = v3(a[3], a[4], a[5]);
+        switch (op) {
+            case 0: { V2 r = rsi(p, d, a[6]); o[0] = r.x; o[1] = r.y; break; }
+            case 1: o[0] = A.get_ozone_density(a[0]); break;
+            case 2: { V3 r = A.get_density(a[0]); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+            case 3: o[0] = A.cloud_phase(a[0], a[1]); break;
+            case 4: o[0] = A.sample_cloud_density(p); break;
+            case 5: o[0] = A.clouds_shadow_od(p, d, a[6]); break;
+            case 6: { V3 r = A.get_ray_transmittance(p, d); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+            case 7: {
+                dm_rng rng = dm_rng_init(A.seed, 0x3000u, (uint32_t)a[14], 2u);
+                V3 sc; float tr, dist;
+                A.clouds_scattering(p, d, v3(a[6], a[7], a[8]), v3(a[9], a[10], a[11]), a[12], a[13], &rng, &sc, &tr, &dist);
+                o[0] = sc.x; o[1] = sc.y; o[2] = sc.z; o[3] = tr; o[4] = dist;
+                break;
+            }
+            case 8: case 9: {
+                dm_rng rng = dm_rng_init(A.seed, 0x3000u, (uint32_t)a[14], 2u);
+                V3 sc, tr;
+                A.atmospheric_scattering(p, d, v3(a[6], a[7], a[8]), v3(a[9], a[10], a[11]), a[12], op - 8, (int)a[13], &rng, &sc, &tr);
+                o[0] = sc.x; o[1] = sc.y; o[2] = sc.z; o[3] = tr.x; o[4] = tr.y; o[5] = tr.z;
+                break;
+            }
+            default: return -1;
+        }
+    }
+    return 0;
+}
 void orc_unit_reservoir_roundtrip(const float* in, float* out) {
     Reservoir r;
     r.init();

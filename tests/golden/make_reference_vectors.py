@@ -499,11 +499,13 @@ def function_vectors(path, n=300, seed=9):
     uv = rng.uniform(0.0, 1.0, (300, 2)).astype(np.float32)
     out["sky_uv_in"] = uv
     out["sky_dir_out"] = np.array([sky.r.atmos.unproject_sky(V(t)).to_list() for t in uv], np.float32)
-    # voxel authoring as the example scripts do it: Scene.round_idx (scene.py:131-137, restated here: the class needs a window) and the
-    # reference's Renderer.set_voxel (pathtracer.py:1325-1328, math_utils.py:86-92) -- ties and near-ties of the rounding, float material
-    # ids (example8.py:7), colours outside [0, 1] and on exact byte fractions
-    global _author_r
-    _author_r = sky.r
+    # voxel authoring as the example scripts do it: the reference's OWN Scene.set_voxel -> Scene.round_idx (scene.py:131-141; the class is
+    # imported from the reference's scene.py, an instance made without its window-opening constructor) -> Renderer.set_voxel
+    # (pathtracer.py:1325-1328, math_utils.py:86-92) -- ties and near-ties of the rounding, float material ids (example8.py:7), colours
+    # outside [0, 1] and on exact byte fractions
+    global _author_scene
+    _author_scene = object.__new__(_reference_scene_class())
+    _author_scene.renderer = sky.r
     A = 1500
     aidx = rng.uniform(-63.4, 62.4, (A, 3))
     aidx[::5] = np.round(aidx[::5]) + rng.choice([0.5, -0.5, 0.49999997, 0.0], (len(aidx[::5]), 3))
@@ -522,18 +524,177 @@ def function_vectors(path, n=300, seed=9):
     print(os.path.basename(path), {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.shape}, flush=True)
 
 
-_author_r = None
+SKY_OPS = {"rsi": (0, 7, 2), "ozone": (1, 1, 1), "density": (2, 1, 3), "cloud_phase": (3, 2, 1), "cloud_density": (4, 3, 1),
+           "cloud_shadow_od": (5, 7, 1), "ray_transmittance": (6, 6, 3), "clouds_scattering": (7, 15, 5),
+           "atmos_scattering_d0": (8, 15, 6), "atmos_scattering_d1": (9, 15, 6)}    # name -> (probe op, floats in, floats out)
+SKY_SEED = 31
 
 
-@taichi.func
-def _round_idx(idx_):
-    idx = taichi.cast(idx_, taichi.f32)
-    return taichi.Vector([taichi.round(idx[0]), taichi.round(idx[1]), taichi.round(idx[2])]).cast(taichi.i32)
+def sky_function_vectors(path, seed=12):
+    """atmos.py one function at a time on random arguments (functions_sky.npz): rsi, get_ozone_density, get_density, cloud_phase,
+    sample_cloud_density, clouds_shadow_od, get_ray_transmittance, clouds_scattering and atmospheric_scattering at both template
+    depths (atmos.py:9-15, 195-349, 355-425, 475-523) -- the whole-table case ref_s6_sky_precompute only meets 64 texels' worth of
+    arguments.  What the functions read besides their arguments is GIVEN: a synthetic transmittance LUT (so that the hour the
+    real one takes is not part of this) and a cloud ambient colour, stored in the file; the cloud tile is the reference's own
+    texture.  Random numbers (the cone sampler of the two scattering functions): stream 2 of (SKY_SEED, frame 0x3000, row)."""
+    import taichi as ti
+    import orc
+    os.chdir(REFERENCE)
+    import renderer.atmos as at
+    from taichi.math import vec3
+    L = orc.lib()
+
+    def dm(op):
+        def f(a, b=0.0):
+            if op == 4 and b == 1.5:
+                return np.float32(a) * np.sqrt(np.float32(a))
+            x, y, out = np.array([a], np.float32), np.array([b], np.float32), np.zeros(1, np.float32)
+            L.orc_unit_detmath(op, 1, orc.fptr(x), orc.fptr(y), orc.fptr(out))
+            return out[0]
+        return f
+    ti.set_elementary(**{n: dm(op) for op, n in enumerate(["sin", "cos", "exp", "log", "pow", "acos", "atan2"])})
+    a = at.Atmos()
+    a.load_textures()
+    rng = np.random.default_rng(seed)
+    R = 6371e3
+    # a smooth positive table in [0, 1] with texel-to-texel variation: every read_trans_lut index matters
+    lut = (0.5 + 0.5 * np.sin(np.arange(256)[:, None, None] * 0.11 + np.arange(128)[None, :, None] * 0.23 + np.arange(3)[None, None, :] * 1.7)) \
+        * rng.uniform(0.6, 1.0, (256, 128, 3))
+    lut = lut.astype(np.float16)
+    a.trans_LUT.a[...] = lut
+    ambient = np.array([0.21, 0.34, 0.55], np.float32)
+    a.cloud_ambient[None] = vec3(*[float(x) for x in ambient])
+    V = lambda x: ti.Vector([np.float32(v) for v in x])  # noqa: E731
+
+    def unit(k, up=None):
+        v = rng.normal(size=(k, 3))
+        if up is not None:
+            v[:, 1] = np.abs(v[:, 1]) * up + (1 - up) * v[:, 1]
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+    def stream(row):
+        out = np.zeros(131072, np.float32)     # (a 64-step depth-0 march draws 42 000 numbers)
+        L.orc_unit_rng(C.c_uint32(SKY_SEED), C.c_uint32(0x3000), C.c_uint32(row), C.c_uint32(2), len(out), orc.fptr(out))
+        return out
+
+    out = dict(trans_lut=lut.view(np.uint16), cloud_ambient=ambient, seed=np.uint32(SKY_SEED))
+    t0 = time.time()
+    # rsi
+    n = 160
+    pos = np.stack([rng.uniform(-5e4, 5e4, n), R + rng.uniform(0, 1.2e5, n), rng.uniform(-5e4, 5e4, n)], 1).astype(np.float32)
+    rad = rng.choice([R, R + 2000.0, R + 2340.0, R + 110e3], n).astype(np.float32)
+    arg = np.concatenate([pos, unit(n), rad[:, None]], 1).astype(np.float32)
+    res = np.zeros((n, 2), np.float32)
+    for k in range(n):
+        res[k] = at.rsi(V(arg[k, 0:3]), V(arg[k, 3:6]), np.float32(arg[k, 6])).to_list()
+    out["rsi_in"], out["rsi_out"] = arg, res
+    # densities
+    h = np.concatenate([rng.uniform(-2e3, 1.3e5, 150), [0.0, 15e3, 25e3, -1.0]]).astype(np.float32)
+    out["ozone_in"], out["density_in"] = h[:, None].copy(), h[:, None].copy()
+    out["ozone_out"] = np.array([[a.get_ozone_density(np.float32(x))] for x in h], np.float32)
+    out["density_out"] = np.array([a.get_density(np.float32(x)).to_list() for x in h], np.float32)
+    # cloud phase
+    arg = np.stack([rng.uniform(-1, 1, 160), rng.choice([1.0, 0.5, 0.25, 0.125], 160)], 1).astype(np.float32)
+    out["cloud_phase_in"] = arg
+    out["cloud_phase_out"] = np.array([[a.cloud_phase(np.float32(x), np.float32(y))] for x, y in arg], np.float32)
+    # cloud density: points in and around the layer (relative height 1 900 .. 2 450 m), over several tiles -- half of them above
+    # texels that hold a cloud (a tenth of the tile does), at a height inside the layer
+    tex = a.cloud_tex.to_numpy().astype(np.float32) / 255.0
+    cloudy = np.argwhere((tex[..., 2] >= 0.7) & ((tex[..., 0] >= 0.7) | (tex[..., 1] >= 0.7)))
+
+    def over_clouds(k, lo, hi):
+        c = cloudy[rng.integers(0, len(cloudy), k)]
+        tile = 29000.0
+        x = (c[:, 0] + rng.uniform(0.1, 0.9, k)) / 256.0 * tile - 0.65 * tile + rng.integers(-1, 2, k) * tile
+        z = (c[:, 1] + rng.uniform(0.1, 0.9, k)) / 256.0 * tile - 0.65 * tile + rng.integers(-1, 2, k) * tile
+        hgt = rng.uniform(lo, hi, k)
+        return np.stack([x, np.sqrt((R + hgt) ** 2 - x * x - z * z), z], 1)
+    n = 200
+    pos = np.stack([rng.uniform(-6e4, 6e4, n), R + rng.uniform(1900.0, 2450.0, n), rng.uniform(-6e4, 6e4, n)], 1)
+    pos[: n // 2] = over_clouds(n // 2, 1950.0, 2400.0)
+    pos = pos.astype(np.float32)
+    out["cloud_density_in"] = pos
+    out["cloud_density_out"] = np.array([[a.sample_cloud_density(V(p))] for p in pos], np.float32)
+    # shadow optical depth: from inside the layer
+    n = 150
+    pos = np.stack([rng.uniform(-4e4, 4e4, n), R + rng.uniform(2000.0, 2340.0, n), rng.uniform(-4e4, 4e4, n)], 1)
+    pos[: 2 * n // 3] = over_clouds(2 * n // 3, 2005.0, 2330.0)
+    pos = pos.astype(np.float32)
+    arg = np.concatenate([pos, unit(n, up=0.8), rng.random((n, 1))], 1).astype(np.float32)
+    out["cloud_shadow_od_in"] = arg
+    out["cloud_shadow_od_out"] = np.array([[a.clouds_shadow_od(V(r[0:3]), V(r[3:6]), np.float32(r[6]))] for r in arg], np.float32)
+    print(f"  small functions {time.time() - t0:.0f} s", flush=True)
+    # ray transmittance: the LUT's own rays and others
+    n = 100
+    th = np.arccos(rng.uniform(-1, 1, n))
+    pos = np.stack([np.zeros(n), R + rng.uniform(0, 1.05e5, n), np.zeros(n)], 1).astype(np.float32)
+    dirs = np.stack([np.sin(th), np.cos(th), np.zeros(n)], 1).astype(np.float32)
+    dirs[n // 2:] = unit(n - n // 2)
+    arg = np.concatenate([pos, dirs], 1).astype(np.float32)
+    out["ray_transmittance_in"] = arg
+    out["ray_transmittance_out"] = np.array([a.get_ray_transmittance(V(r[0:3]), V(r[3:6])).to_list() for r in arg], np.float32)
+    print(f"  ray transmittance {time.time() - t0:.0f} s", flush=True)
+
+    def sun_rows(n):
+        d = unit(n, up=0.9)
+        sun = unit(n, up=0.7)
+        col = rng.uniform(0.5, 4.0, (n, 3))
+        cosm = np.cos(rng.choice([0.0125, 0.05, 0.2], n))
+        return d, np.concatenate([sun, col, cosm[:, None], np.zeros((n, 1)), np.arange(n)[:, None]], 1)
+    # clouds_scattering from the camera position (atmos.py:149)
+    n = 48
+    d, rest = sun_rows(n)
+    rest[:, 7] = rng.random(n)      # (this function's 14th argument is the dither, not a step count)
+    arg = np.concatenate([np.tile(np.array([[0.0, R + 1e3, 0.0]]), (n, 1)), d, rest], 1).astype(np.float32)
+    res = np.zeros((n, 5), np.float32)
+    for k in range(n):
+        ti.set_random_source(stream(k))
+        r = arg[k]
+        sc, tr, dist = a.clouds_scattering(V(r[0:3]), V(r[3:6]), V(r[6:9]), V(r[9:12]), np.float32(r[12]), np.float32(r[13]))
+        res[k] = sc.to_list() + [tr, dist]
+    out["clouds_scattering_in"], out["clouds_scattering_out"] = arg, res
+    print(f"  clouds_scattering {time.time() - t0:.0f} s", flush=True)
+    # atmospheric_scattering: template depth 1 with its 5 steps (atmos.py:409) and other counts, depth 0 with few steps and with the real 64
+    for name, depth, counts in (("atmos_scattering_d1", 1, [5] * 60 + [3] * 10 + [9] * 10), ("atmos_scattering_d0", 0, [2] * 8 + [5] * 4 + [64] * 2)):
+        n = len(counts)
+        d, rest = sun_rows(n)
+        rest[:, 7] = counts
+        pos = np.stack([rng.uniform(-3e4, 3e4, n), R + rng.uniform(500.0, 6e4, n), rng.uniform(-3e4, 3e4, n)], 1)
+        pos[: n // 3] = [0.0, R + 1e3, 0.0]
+        arg = np.concatenate([pos, d, rest], 1).astype(np.float32)
+        res = np.zeros((n, 6), np.float32)
+        for k in range(n):
+            ti.set_random_source(stream(k))
+            r = arg[k]
+            sc, tr = a.atmospheric_scattering(V(r[0:3]), V(r[3:6]), V(r[6:9]), V(r[9:12]), np.float32(r[12]), depth, int(r[13]))
+            res[k] = sc.to_list() + tr.to_list()
+            if depth == 0:
+                print(f"    depth 0, {int(r[13])} steps: {time.time() - t0:.0f} s", flush=True)
+        out[name + "_in"], out[name + "_out"] = arg, res
+    np.savez_compressed(path, **out)
+    print("functions_sky", {k: v.shape for k, v in out.items() if hasattr(v, "shape")}, os.path.getsize(path), "bytes", f"{time.time() - t0:.0f} s", flush=True)
+
+
+_author_scene = None
+
+
+def _reference_scene_class():
+    """`Scene` of /root/reference/scene.py, imported from where it lies.  (scene.py:23 reaches into Taichi for a window-system handle
+    that only its interactive loop uses: an empty module stands in for that import.)"""
+    import importlib.util
+    import types
+    for name in ("taichi.lang", "taichi.lang.impl"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["taichi.lang.impl"]._ti_core = None
+    spec = importlib.util.spec_from_file_location("reference_scene", os.path.join(REFERENCE, "scene.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.Scene
 
 
 @taichi.kernel
 def _author(i: taichi.f32, j: taichi.f32, k: taichi.f32, mat: taichi.f32, cr: taichi.f32, cg: taichi.f32, cb: taichi.f32):
-    _author_r.set_voxel(_round_idx(taichi.Vector([i, j, k])), mat, taichi.Vector([cr, cg, cb]))
+    _author_scene.set_voxel(taichi.Vector([i, j, k]), mat, taichi.Vector([cr, cg, cb]))
 
 
 def config_of(case):
@@ -612,15 +773,26 @@ def main(argv):
     if "--check-golden" in argv:
         return check_golden([a for a in argv if not a.startswith("--")])
     libm = "--libm" in argv
-    names = [a for a in argv if not a.startswith("--")] or list(CASES) + ["rays", "functions"]
+    names = [a for a in argv if not a.startswith("--")] or list(CASES) + ["rays", "functions", "functions_sky"]
     os.makedirs(OUT, exist_ok=True)
     if "rays" in names:
         names.remove("rays")
         if not os.path.exists(os.path.join(OUT, "rays_sunlit.npz")) or "--force" in argv:
             ray_vectors(os.path.join(OUT, "rays_sunlit.npz"))
+    if "functions_sky" in names:
+        names.remove("functions_sky")
+        if not os.path.exists(os.path.join(OUT, "functions_sky.npz")) or "--force" in argv:
+            sky_function_vectors(os.path.join(OUT, "functions_sky.npz"))
     if "functions" in names:
         names.remove("functions")
-        if not os.path.exists(os.path.join(OUT, "functions.npz")) or "--force" in argv:
+        if "--verify" in argv:      # into a scratch file, compared array by array with the committed one
+            import tempfile
+            tmp = os.path.join(tempfile.mkdtemp(), "functions.npz")
+            function_vectors(tmp)
+            a, b = np.load(tmp), np.load(os.path.join(OUT, "functions.npz"))
+            same = sorted(a.files) == sorted(b.files) and all(np.array_equal(a[k].view(np.uint8) if a[k].dtype.kind == "f" else a[k], b[k].view(np.uint8) if b[k].dtype.kind == "f" else b[k]) for k in b.files)
+            print(f"functions: the committed fixture is {'reproduced' if same else 'NOT reproduced'}", flush=True)
+        elif not os.path.exists(os.path.join(OUT, "functions.npz")) or "--force" in argv:
             function_vectors(os.path.join(OUT, "functions.npz"))
     for name in names:
         case = CASES[name]

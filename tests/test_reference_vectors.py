@@ -60,7 +60,7 @@ DENSE = sorted(n for n in CASES if "undefined_px" in np.load(os.path.join(HERE, 
 
 def test_every_case_has_a_fixture():
     have = {f[:-4] for f in os.listdir(os.path.join(HERE, "golden", "reference")) if f.endswith(".npz")}
-    have -= {"rays_sunlit", "functions"}    # single rays and single functions: the two tests at the end
+    have -= {"rays_sunlit", "functions", "functions_sky"}    # single rays and single functions: the tests at the end
     assert have == set(CASES)
 
 
@@ -237,6 +237,71 @@ def test_oracle_functions_equal_reference_source():
         L.orc_unit_unproject_sky(C.c_void_p(o._ctx), f(np.ascontiguousarray(v["sky_uv_in"][k])), f(out))
         assert _same(out, v["sky_dir_out"][k]), ("unproject_sky", k)
     o.close()
+
+
+SKY_OPS = {"rsi": (0, 2), "ozone": (1, 1), "density": (2, 3), "cloud_phase": (3, 1), "cloud_density": (4, 1), "cloud_shadow_od": (5, 1),
+           "ray_transmittance": (6, 3), "clouds_scattering": (7, 5), "atmos_scattering_d0": (8, 6), "atmos_scattering_d1": (9, 6)}   # name -> (probe op, floats out)
+
+
+def _sky_inputs():
+    from voxel_rt2_amd import host
+    v = np.load(os.path.join(HERE, "golden", "reference", "functions_sky.npz"))
+    cloud = np.load(os.path.join(os.path.dirname(HERE), "voxel_rt2_amd", "data", "cloud_texture.npy"))
+    cfg = host.make_config(16, 8, max_depth=2, sky_res=64, seed=int(v["seed"]))
+    return v, cloud, cfg
+
+
+def _check_sky(v, run):
+    """run(op, rows of arguments, floats per result) -> results; every row of every function, bit for bit (any NaN equals any NaN)."""
+    interesting = 0
+    for name, (op, n_out) in SKY_OPS.items():
+        got = run(op, np.ascontiguousarray(v[name + "_in"], np.float32), n_out)
+        want = v[name + "_out"]
+        bad = [k for k in range(len(want)) if not _same(got[k], want[k])]
+        assert not bad, f"{name}: {len(bad)} of {len(want)} rows differ, first {bad[:3]}: got {got[bad[0]]}, reference {want[bad[0]]}"
+        interesting += int((np.abs(want) > 0).any(axis=1).sum() > len(want) // 4)
+    assert interesting == len(SKY_OPS)      # no function was only ever asked for zeros
+
+
+def test_oracle_sky_functions_equal_reference_source():
+    """functions_sky.npz: atmos.py one function at a time (make_reference_vectors.sky_function_vectors: rsi, the density profiles, the
+    cloud tile lookup, the cloud shadow march, cloud_phase, get_ray_transmittance, clouds_scattering and atmospheric_scattering at both
+    template depths -- atmos.py:9-15, 195-349, 355-425, 475-523) against the oracle's orc_unit_atmos probe, bit for bit."""
+    import ctypes as C
+    v, cloud, cfg = _sky_inputs()
+    o = orc.Oracle(cfg, threads=1)
+    o.upload_cloud_texture(cloud)
+    L, f = orc.lib(), orc.fptr
+    L.orc_set_trans_lut(C.c_void_p(o._ctx), f(np.ascontiguousarray(v["trans_lut"])))
+    L.orc_set_cloud_ambient(C.c_void_p(o._ctx), f(np.ascontiguousarray(v["cloud_ambient"])))
+
+    def run(op, args, n_out):
+        out = np.zeros((len(args), n_out), np.float32)
+        assert L.orc_unit_atmos(C.c_void_p(o._ctx), op, len(args), f(args), args.shape[1], f(out), n_out) == 0
+        return out
+    _check_sky(v, run)
+    o.close()
+
+
+@pytest.mark.gpu
+def test_gpu_sky_functions_equal_reference_source():
+    """The same rows through the device functions of vrt_sky_kernels.hip (vrt_sky_probe, include/vrt_api.h)."""
+    import ctypes as C
+    from voxel_rt2_amd import _lib
+    from voxel_rt2_amd._session import NativeSession
+    v, cloud, cfg = _sky_inputs()
+    lib = _lib.load()
+    g = NativeSession(lib, "vrt_", cfg)
+    g.upload_cloud_texture(cloud)
+    lut, amb = np.ascontiguousarray(v["trans_lut"]), np.ascontiguousarray(v["cloud_ambient"])
+
+    def run(op, args, n_out):
+        out = np.zeros((len(args), n_out), np.float32)
+        rc = lib.vrt_sky_probe(C.c_void_p(g._ctx), op, len(args), orc.fptr(args), args.shape[1], orc.fptr(out), n_out, orc.fptr(lut), orc.fptr(amb))
+        assert rc == 0, lib.vrt_last_error()
+        return out
+    _check_sky(v, run)
+    g.close()
 
 
 def test_voxel_authoring_equals_reference_source():

@@ -114,6 +114,8 @@ def _open(path):
     lib.vrt_reset_stats.argtypes = [C.c_void_p]
     lib.vrt_detmath_probe.restype = C.c_int
     lib.vrt_detmath_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vrt_sky_probe.restype = C.c_int
+    lib.vrt_sky_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     return lib
 
 

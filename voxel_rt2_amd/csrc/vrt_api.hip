@@ -1214,6 +1214,26 @@ int vrt_reset_stats(vrt_ctx* c) {
     memset(&c->stats, 0, sizeof(c->stats));
     return VRT_OK;
 }
+// Test hook: rows of arguments through single functions of the sky precompute (vrt_sky_kernels.hip, k_sky_probe).
+int vrt_sky_probe(vrt_ctx* c, int op, int n, const float* in, int in_stride, float* out, int out_stride, const uint16_t* trans_lut, const float* cloud_ambient) {
+    if (!c || !in || !out || n <= 0 || in_stride <= 0 || out_stride <= 0 || op < 0 || op > 9) return fail(VRT_E_INVALID, "bad argument");
+    if (c->cfg.sky_res <= 0) return fail(VRT_E_STATE, "context was created without sky tables (sky_res = 0)");
+    HIP_TRY(hipSetDevice(c->device));
+    c->main_dirty = true;
+    if (trans_lut) HIP_TRY(hipMemcpyAsync(c->d_trans_lut, trans_lut, 256 * 128 * 3 * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    float *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_in, (size_t)n * in_stride * sizeof(float)));
+    if (hipMalloc((void**)&d_out, (size_t)n * out_stride * sizeof(float)) != hipSuccess) { hipFree(d_in); return fail(VRT_E_DEVICE, "no memory for the probe"); }
+    const f3 amb = cloud_ambient ? mk3(cloud_ambient[0], cloud_ambient[1], cloud_ambient[2]) : mk3(0.0f);
+    hipError_t e = hipMemcpyAsync(d_in, in, (size_t)n * in_stride * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, (size_t)n * out_stride * sizeof(float), c->stream);
+    if (e == hipSuccess) e = launch_sky_probe(c->stream, make_sky(c), op, n, d_in, in_stride, d_out, out_stride, amb);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n * out_stride * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_in); hipFree(d_out);
+    if (e != hipSuccess) return fail(VRT_E_DEVICE, std::string("sky probe: ") + hipGetErrorString(e));
+    return VRT_OK;
+}
 // diagnostic builds (-DVRT_DIAG_REGIONS) only: 32 x {wave entries, active lanes} per instrumented code region
 int vrt_diag_regions(vrt_ctx* c, unsigned long long* out64, int reset) {
     if (!c || !out64) return fail(VRT_E_INVALID, "null argument");

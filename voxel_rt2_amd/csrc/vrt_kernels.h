@@ -74,6 +74,7 @@ struct SkyPrecompute {
     int use_clouds;
     uint32_t seed;
 };
+hipError_t launch_sky_probe(hipStream_t st, const SkyPrecompute& sp, int op, int n, const float* in, int in_stride, float* out, int out_stride, f3 ambient);
 hipError_t launch_sky_prepare(hipStream_t st, const SkyPrecompute& sp, f3 sun_dir, f3 sun_col, float sun_cos);
 hipError_t launch_sky_clouds(hipStream_t st, const SkyPrecompute& sp, f3 sun_dir, f3 sun_col, float sun_cos, int max_samples,
                              uint32_t pass, int u0, int u1);   // table columns [u0, u1)

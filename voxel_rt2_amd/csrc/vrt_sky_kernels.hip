@@ -80,17 +80,8 @@ __device__ __forceinline__ f3 read_trans_lut(const uint16_t* lut, float cos_thet
     return mk3(dm_f16_to_f32(p[0]), dm_f16_to_f32(p[1]), dm_f16_to_f32(p[2]));
 }
 
-// atmos.py:462-498
-__global__ void k_trans_lut(uint16_t* lut) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 256 * 128) return;
-    int x = i >> 7, y = i & 127;
-    const AtmosConst c = atmos_const();
-    float cos_theta = ((float)x / 256.0f) * 2.0f - 1.0f;
-    float h = ATMOS_H * (float)y / 128.0f;
-    float sin_theta = dm_sin(dm_acos(cos_theta));
-    f3 dir = mk3(sin_theta, cos_theta, 0.0f);
-    f3 pos = mk3(0.0f, PLANET_R + h, 0.0f);
+// atmos.py:475-498
+__device__ f3 ray_transmittance(const AtmosConst& c, f3 pos, f3 dir) {
     float step_delta = rsi(pos, dir, (float)(6371e3 + 110e3)).y * (1.0f / 128.0f);
     f3 step = dir * step_delta;
     pos = pos + step * (0.5f * (dm_max(dir.y, 0.0f) * 0.5f + 0.5f));
@@ -102,6 +93,18 @@ __global__ void k_trans_lut(uint16_t* lut) {
     od = extinc_mul(c, od);
     f3 T = mk3(dm_exp(-od.x), dm_exp(-od.y), dm_exp(-od.z));
     if (rsi(pos, dir, PLANET_R).x > 0.0f) T = T * 0.0f;
+    return T;
+}
+// atmos.py:462-473
+__global__ void k_trans_lut(uint16_t* lut) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 256 * 128) return;
+    int x = i >> 7, y = i & 127;
+    const AtmosConst c = atmos_const();
+    float cos_theta = ((float)x / 256.0f) * 2.0f - 1.0f;
+    float h = ATMOS_H * (float)y / 128.0f;
+    float sin_theta = dm_sin(dm_acos(cos_theta));
+    const f3 T = ray_transmittance(c, mk3(0.0f, PLANET_R + h, 0.0f), mk3(sin_theta, cos_theta, 0.0f));
     lut[3 * i] = dm_f32_to_f16(T.x);
     lut[3 * i + 1] = dm_f32_to_f16(T.y);
     lut[3 * i + 2] = dm_f32_to_f16(T.z);
@@ -218,24 +221,16 @@ __device__ __forceinline__ float cloud_phase(float ct, float an) {  // atmos.py:
     return lerp1(lerp1(front, back, 0.5f), peak, 0.15f);
 }
 
-// atmos.py:140-157 + 269-349
-__global__ __launch_bounds__(256) void k_sky_clouds(SkyPrecompute sp, f3 sun_dir, f3 sun_col, float sun_cos, int max_samples, uint32_t pass, int u0, int u1) {
-    const int v = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int u = u0 + blockIdx.y * 4 + (threadIdx.x >> 6);   // columns [u0, u1): a texel depends on no other (atmos.py:140-157)
-    if (u >= u1 || v >= sp.res) return;
-    const SunArgs sun = make_sun(sun_dir, sun_col, sun_cos);
-    const f3 ambient = mk3(sp.cloud_ambient[0], sp.cloud_ambient[1], sp.cloud_ambient[2]);
-    dm_rng rng = dm_rng_init(sp.seed, pass, (uint32_t)(u * sp.res + v), 2u);
-    const f3 dir = unproject_sky(sp.fres, mk2(((float)u + 0.5f) * sp.fres, ((float)v + 0.5f) * sp.fres));
-    const float dither = dm_rng_f32(&rng);
-    const f3 origin = sky_cam_pos();
-
+// atmos.py:269-349
+__device__ void clouds_scattering(const SkyPrecompute& sp, const SunArgs& sun, f3 ambient, f3 origin, f3 dir, float dither, dm_rng& rng,
+                                  f3& in_scatter, float& transmittance, float& weighted_dist) {
     const float fsteps = 1.0f / 32.0f;
     float bottom = rsi(origin, dir, (float)(6371e3 + 0e3 + 2000.0)).y;
     float top = rsi(origin, dir, (float)(6371e3 + 0e3 + 2000.0 + 340.0)).y;
-    float transmittance = 1.0f;
-    f3 in_scatter = mk3(0.0f);
-    float weight_sum = 0.0f, weighted_dist = 0.0f;
+    transmittance = 1.0f;
+    in_scatter = mk3(0.0f);
+    float weight_sum = 0.0f;
+    weighted_dist = 0.0f;
     f3 start = origin + dir * bottom;
     float step_delta = (top - bottom) * fsteps;
     f3 step = dir * step_delta;
@@ -279,6 +274,21 @@ __global__ __launch_bounds__(256) void k_sky_clouds(SkyPrecompute sp, f3 sun_dir
         weight_sum += transmittance;
     }
     weighted_dist /= weight_sum;
+}
+
+// atmos.py:140-157
+__global__ __launch_bounds__(256) void k_sky_clouds(SkyPrecompute sp, f3 sun_dir, f3 sun_col, float sun_cos, int max_samples, uint32_t pass, int u0, int u1) {
+    const int v = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int u = u0 + blockIdx.y * 4 + (threadIdx.x >> 6);   // columns [u0, u1): a texel depends on no other (atmos.py:140-157)
+    if (u >= u1 || v >= sp.res) return;
+    const SunArgs sun = make_sun(sun_dir, sun_col, sun_cos);
+    const f3 ambient = mk3(sp.cloud_ambient[0], sp.cloud_ambient[1], sp.cloud_ambient[2]);
+    dm_rng rng = dm_rng_init(sp.seed, pass, (uint32_t)(u * sp.res + v), 2u);
+    const f3 dir = unproject_sky(sp.fres, mk2(((float)u + 0.5f) * sp.fres, ((float)v + 0.5f) * sp.fres));
+    const float dither = dm_rng_f32(&rng);
+    f3 in_scatter;
+    float transmittance, weighted_dist;
+    clouds_scattering(sp, sun, ambient, sky_cam_pos(), dir, dither, rng, in_scatter, transmittance, weighted_dist);
 
     in_scatter = in_scatter * 1.2f;
     const float fmax = 1.0f / (float)max_samples;
@@ -320,8 +330,50 @@ __global__ __launch_bounds__(256) void k_sky_slice(SkyPrecompute sp, f3 sun_dir,
     tr[0] = tout.x; tr[1] = tout.y; tr[2] = tout.z;
 }
 
+// Test hook (vrt_sky_probe): one function of this file per row of arguments, as oracle/orc_api.cpp's orc_unit_atmos lays them out.
+__global__ void k_sky_probe(SkyPrecompute sp, int op, int n, const float* in, int in_stride, float* out, int out_stride, f3 ambient) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float* a = in + (size_t)k * in_stride;
+    float* o = out + (size_t)k * out_stride;
+    const AtmosConst c = atmos_const();
+    const f3 p = mk3(a[0], a[1], a[2]), d = mk3(a[3], a[4], a[5]);
+    switch (op) {
+        case 0: { const f2 r = rsi(p, d, a[6]); o[0] = r.x; o[1] = r.y; break; }
+        case 1: o[0] = ozone_density(a[0]); break;
+        case 2: { const f3 r = density_at(a[0]); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+        case 3: o[0] = cloud_phase(a[0], a[1]); break;
+        case 4: o[0] = cloud_density_at(sp, p); break;
+        case 5: o[0] = cloud_shadow_od(sp, p, d, a[6]); break;
+        case 6: { const f3 r = ray_transmittance(c, p, d); o[0] = r.x; o[1] = r.y; o[2] = r.z; break; }
+        case 7: {
+            const SunArgs sun = make_sun(mk3(a[6], a[7], a[8]), mk3(a[9], a[10], a[11]), a[12]);
+            dm_rng rng = dm_rng_init(sp.seed, 0x3000u, (uint32_t)a[14], 2u);
+            f3 sc;
+            float tr, dist;
+            clouds_scattering(sp, sun, ambient, p, d, a[13], rng, sc, tr, dist);
+            o[0] = sc.x; o[1] = sc.y; o[2] = sc.z; o[3] = tr; o[4] = dist;
+            break;
+        }
+        case 8: case 9: {
+            const SunArgs sun = make_sun(mk3(a[6], a[7], a[8]), mk3(a[9], a[10], a[11]), a[12]);
+            dm_rng rng = dm_rng_init(sp.seed, 0x3000u, (uint32_t)a[14], 2u);
+            f3 sc, tr;
+            if (op == 8) atmospheric_scattering<0>(sp, c, sun, p, d, (int)a[13], rng, sc, tr);
+            else atmospheric_scattering<1>(sp, c, sun, p, d, (int)a[13], rng, sc, tr);
+            o[0] = sc.x; o[1] = sc.y; o[2] = sc.z; o[3] = tr.x; o[4] = tr.y; o[5] = tr.z;
+            break;
+        }
+    }
+}
+
 #define VRT_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
+hipError_t launch_sky_probe(hipStream_t st, const SkyPrecompute& sp, int op, int n, const float* in, int in_stride, float* out, int out_stride, f3 ambient) {
+    hipLaunchKernelGGL(k_sky_probe, dim3((n + 63) / 64), dim3(64), 0, st, sp, op, n, in, in_stride, out, out_stride, ambient);
+    VRT_LAUNCH_CHECK();
+    return hipSuccess;
+}
 hipError_t launch_sky_prepare(hipStream_t st, const SkyPrecompute& sp, f3 sun_dir, f3 sun_col, float sun_cos) {
     hipLaunchKernelGGL(k_trans_lut, dim3(256 * 128 / 256), dim3(256), 0, st, sp.trans_lut);
     VRT_LAUNCH_CHECK();
