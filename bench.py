@@ -241,7 +241,7 @@ class ShardedRun:
 
     N_TILES = 8   # deeper than the library's launch pipeline (eight launches in flight on a shard of an eighth of 1080p)
 
-    def __init__(self, lib, dist, torch, *, scene, W, H, depth, spp, grid=128, rank=0, world=1, local_rank=0, rehearse=False, balance=False):
+    def __init__(self, lib, dist, torch, *, scene, W, H, depth, spp, grid=128, rank=0, world=1, local_rank=0, rehearse=False, balance=False, stripes=0):
         from voxel_rt2_amd import host, parallel
         from voxel_rt2_amd._session import NativeSession
         self.lib, self.dist, self.torch, self.parallel = lib, dist, torch, parallel
@@ -250,10 +250,14 @@ class ShardedRun:
         self.stream = torch.cuda.Stream()   # the context's stream: temporal passes (the render launches go to the library's own)
         self.coll_dev = "cpu" if rehearse else "cuda"
 
+        self.stripes = stripes if world > 1 else 0   # rows per interleaved stripe (vrt_set_row_stripes) instead of contiguous tiles
+
         def make_session(rows):
             cfg = host.make_config(W, H, voxel_edges=self.params["voxel_edges"], exposure=self.params["exposure"], max_depth=depth,
-                                   seed=SEED, device=local_rank, rows=rows if world > 1 else None, grid_res=grid)
+                                   seed=SEED, device=local_rank, rows=rows if (world > 1 and not self.stripes) else None, grid_res=grid)
             s = NativeSession(lib, "vrt_", cfg)
+            if self.stripes and rows is not None:
+                s.set_row_stripes(self.stripes, world, rank)
             s.set_stream(self.stream.cuda_stream)
             parallel.configure_session(s, world)   # N > 1: leave workgroup slots free for RCCL's kernels
             setup_session(s, self.mat, self.rgb, self.params)
@@ -263,7 +267,7 @@ class ShardedRun:
         # Row tiles: start from an equal split, then (untimed) let every rank measure its tile's device time and move the
         # tile boundaries so that all ranks carry the same cost -- the sky rows of S1 cost a fraction of the floor rows.
         self.bounds = split_rows(H, world)
-        if balance and world > 1:
+        if balance and world > 1 and not self.stripes:
             user_overlap = os.environ.get("VRT_OVERLAP")
             os.environ["VRT_OVERLAP"] = "0"  # isolated launches while measuring (the library reads it when a context is created)
             self.sess = make_session(self.bounds[rank])
@@ -286,8 +290,13 @@ class ShardedRun:
         self.sess = make_session(self.bounds[rank])
         self.steps_done = 0
         self.tiles_gathered = 0
+        # rows of the frame every rank produces, in the order its tile holds them
+        self.rank_rows = [np.arange(a, b) for a, b in self.bounds]
+        if self.stripes:
+            period = self.stripes * world
+            self.rank_rows = [np.concatenate([np.arange(a, min(a + self.stripes, H)) for a in range(r * self.stripes, H, period)]) for r in range(world)]
         if world > 1:
-            max_rows = max(b - a for a, b in self.bounds)
+            max_rows = max(len(r) for r in self.rank_rows)
             # every rank's tile is padded to the tallest: the library writes the rank's own rows at the top of its tile
             self.tiles = [torch.zeros((max_rows, W, 3), dtype=torch.float32, device="cuda") for _ in range(self.N_TILES)]
             self.gathered = [torch.zeros_like(self.tiles[0]) for _ in range(world)] if rank == 0 else None
@@ -364,7 +373,9 @@ class ShardedRun:
 
     def check_against_unsharded(self, label):
         """Rehearsal only (rank 0): the frame assembled from the LAST gathered tiles equals an unsharded render of the same steps."""
-        full = np.concatenate([self.gathered[r][: self.bounds[r][1] - self.bounds[r][0]].cpu().numpy() for r in range(self.world)], axis=0)
+        full = np.zeros((self.H, self.W, 3), np.float32)
+        for r in range(self.world):
+            full[self.rank_rows[r]] = self.gathered[r][: len(self.rank_rows[r])].cpu().numpy()
         one = self.make_full_session()
         for _ in range(self.steps_done):
             one.accumulate(self.spp)
@@ -458,7 +469,9 @@ def main():
 
     scene = scenes.scene_s1(0)
     mat, rgb, params = scene
-    run = ShardedRun(lib, dist, torch, scene=scene, W=WIDTH, H=HEIGHT, depth=MAX_DEPTH, spp=SPP_PER_STEP, balance=True, **common)
+    # VRT_BENCH_STRIPES=S: interleaved stripes of S rows (vrt_set_row_stripes) instead of cost-balanced contiguous row tiles
+    stripes = int(os.environ.get("VRT_BENCH_STRIPES", "0"))
+    run = ShardedRun(lib, dist, torch, scene=scene, W=WIDTH, H=HEIGHT, depth=MAX_DEPTH, spp=SPP_PER_STEP, balance=True, stripes=stripes, **common)
     elapsed, st = run.timed(args.steps, args.warmup)
     if rehearse and world > 1 and rank == 0:
         run.check_against_unsharded("config 2")
@@ -492,10 +505,11 @@ def main():
                        "max_depth": MAX_DEPTH, "seed": SEED, "build_id": lib.vrt_build_id().decode(),
                        "launch_pipeline": {"overlapped": bool(flags & 1), "dispatch_gate": bool(flags & 2), "gate_host_releases": int(flags >> 8),
                                            "launches_in_flight": 2 * int((flags >> 2) & 7), "workgroup_slots_per_launch": f"1/{max(int((flags >> 5) & 7), 1)}"},
-                       "sharding": (f"{world} contiguous row tiles, boundaries balanced by measured tile cost, HDR tile written by the temporal pass into a ring "
+                       "sharding": ((f"{world} sets of interleaved {stripes}-row stripes (every rank renders row stripes spread over the whole frame, two more rows either side of each), "
+                                     if stripes else f"{world} contiguous row tiles, boundaries balanced by measured tile cost, ") + "HDR tile written by the temporal pass into a ring "
                                     f"of {ShardedRun.N_TILES} device tiles, RCCL gather of every step's tile (issued when its pass is queued, all inside the "
                                     f"timed region), {parallel.reserved_cus(world)} CUs' worth of workgroup slots left free for the collective; "
-                                    f"tile rows {[b - a for a, b in bounds]}") if world > 1 else "none"},
+                                    f"tile rows {[len(r) for r in run.rank_rows]}") if world > 1 else "none"},
             "roofline": roofline_block(render_kernel, avg_ms, samples_per_launch, render_bytes(work["reference"]), render_bytes(work["timed"]),
                                        counters.get("config2_s1_1080p", {}), note, elapsed / launches * 1e3),
             "work_per_path_sample": {k: {a: round(b, 3) for a, b in v.items()} for k, v in work.items()},
@@ -524,7 +538,7 @@ def main():
                     continue
                 sc_ = scenes.SCENES[case["scene"]](12345)
                 sc_ = (sc_[0], sc_[1], dict(sc_[2], use_physical_sky=0, use_clouds=0))
-                r2 = ShardedRun(lib, dist, torch, scene=sc_, W=case["W"], H=case["H"], depth=case["depth"], spp=case["spp"], grid=case.get("grid", 128), **common)
+                r2 = ShardedRun(lib, dist, torch, scene=sc_, W=case["W"], H=case["H"], depth=case["depth"], spp=case["spp"], grid=case.get("grid", 128), stripes=stripes, **common)
                 steps = 2 if rehearse else case["steps"]
                 el, st2 = r2.timed(steps, 1)
                 if rehearse and rank == 0:
@@ -536,7 +550,7 @@ def main():
                                 "metric": "Mpath-samples/sec", "unit": "Mpath-samples/s", "value": round(px * case["spp"] * steps / el / 1e6, 2),
                                 "n_gpus": world, "steps": steps, "ms_per_step": round(el / steps * 1e3, 4),
                                 "kernel_ms_per_launch": {"render": round(st2["render_ms"] / max(st2["render_launches"], 1), 4)},
-                                "tile_rows": [b - a for a, b in r2.bounds]})
+                                "tile_rows": [len(r) for r in r2.rank_rows]})
                 r2.close()
     if rank == 0:
         out["secondary"] = sec

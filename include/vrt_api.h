@@ -180,6 +180,15 @@ int vrt_host_free(vrt_ctx* ctx, void* ptr);
  * caller keeps in flight. */
 int vrt_set_hdr_targets(vrt_ctx* ctx, void* const* device_ptrs, int n);
 int vrt_hdr_targets_written(vrt_ctx* ctx, uint64_t* count);
+/* Multi-GPU partition by INTERLEAVED ROW STRIPES instead of contiguous row tiles ("prefer interleaved 8-row stripes
+ * (row_tile % 8 == rank) if contiguous tiles miss the target"): a whole-frame context (row_begin = row_end = 0) produces, of every
+ * stripe_rows * n_parts rows, the stripe_rows rows starting at part * stripe_rows -- every rank then carries the frame's average
+ * cost by construction, without a balancing pass.  stripe_rows is a multiple of 8 (the pixel tile, pathtracer.py:74); each stripe
+ * is rendered with two more rows either side (what the accumulation pass reads of its neighbours: (stripe_rows + 4) / stripe_rows
+ * of the work -- 32 rows: +12.5 %).  Buffers stay frame-sized; vrt_fetch_hdr returns the frame with the other rows zero;
+ * vrt_fetch_hdr_device / the tiles of vrt_set_hdr_targets hold the context's rows stripe after stripe.  Static camera, ReSTIR off.
+ * Call before the first vrt_accumulate; stripe_rows = 0 turns it off.  No counterpart in the reference (one GPU). */
+int vrt_set_row_stripes(vrt_ctx* ctx, int stripe_rows, int n_parts, int part);
 int vrt_fetch_buffer(vrt_ctx* ctx, int which, void* out);
 int vrt_sync(vrt_ctx* ctx);
 int vrt_get_stats(vrt_ctx* ctx, vrt_stats* out);

@@ -171,6 +171,23 @@ int emu_set_scene(Emu* c, const vrt_scene_params* s) { c->scene = *s; return 0; 
 int emu_set_camera(Emu* c, const vrt_camera* cam) { c->cam = *cam; return 0; }
 int emu_prepare(Emu*) { return 0; }
 int emu_set_reference_indexing(Emu* c, int on) { c->ref_oob = on != 0; return 0; }
+// The rows a striped launch renders (vrt_set_row_stripes): the render kernels' enumeration -- tile rows through launch_tile_row(), pixels
+// through launch_renders_row() (vrt_types.h) -- marked in out[H].  Returns the number of tile rows enumerated.
+int emu_unit_stripe_rows(int H, int stripe_rows, int n_parts, int part, uint8_t* out) {
+    FrameParams fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.H = H; fp.row0 = 0; fp.row1 = H;
+    fp.stripe_rows = stripe_rows; fp.stripe_period = stripe_rows * n_parts; fp.stripe_first = part * stripe_rows;
+    int n = 0;
+    for (int s0 = fp.stripe_first; s0 < H; s0 += fp.stripe_period) n++;
+    fp.stripe_tile_rows = n * (stripe_rows / 8 + 2);
+    for (int t = 0; t < launch_tile_rows(fp); t++)
+        for (int r = 0; r < 8; r++) {
+            const int v = launch_tile_row(fp, t) + r;
+            if (v < fp.row1 && launch_renders_row(fp, v)) out[v] += 1;
+        }
+    return launch_tile_rows(fp);
+}
 int emu_upload_sky(Emu* c, const float* scat, const float* trans) {
     memcpy(c->sky_scat.data(), scat, c->sky_scat.size() * 4);
     memcpy(c->sky_trans.data(), trans, c->sky_trans.size() * 4);

@@ -13,8 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_rehearsal():
-    env = dict(os.environ, VRT_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
+@pytest.mark.parametrize("stripes", [0, 32])
+def test_bench_two_ranks_rehearsal(stripes):
+    """stripes = 32: the same run with the frame split into interleaved 32-row stripes (vrt_set_row_stripes) instead of two contiguous
+    row tiles -- SURVEY.md 8e's fallback partition."""
+    env = dict(os.environ, VRT_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1", VRT_BENCH_STRIPES=str(stripes))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     import socket
@@ -34,6 +37,7 @@ def test_bench_two_ranks_rehearsal():
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 2 and out["value"] > 0
     assert out["cpu_baseline"] is None and out["roofline"]["traffic"] is None
     assert sum(int(x) for x in out["config"]["sharding"].split("[")[1].split("]")[0].split(",")) == 1080
+    assert ("interleaved 32-row stripes" in out["config"]["sharding"]) == (stripes == 32)
     sec = {s["name"]: s for s in out["secondary"]}
     assert set(sec) == {"config4_dense_4k_2gpu", "config5_dense256_4k_2gpu"}
     for s in sec.values():

@@ -171,3 +171,25 @@ def test_degenerate_grids(fill):
         orc.setup(s, mat, rgb, params)
         s.accumulate(2)
     assert_same(o, e)
+
+
+def test_row_stripe_enumeration_covers_its_rows_once():
+    """vrt_set_row_stripes: the render kernels' tile-row enumeration (launch_tile_row / launch_renders_row, vrt_types.h) visits exactly
+    the part's stripes plus two rows either side, each row once; the parts' own stripes tile the frame."""
+    import ctypes as C
+    lib = emu.lib()
+    for H, S, N in ((1080, 8, 8), (1080, 32, 8), (2160, 64, 8), (100, 8, 3), (136, 32, 2), (72, 16, 5), (8, 8, 1)):
+        owned_all = np.zeros(H, int)
+        for part in range(N):
+            out = np.zeros(H, np.uint8)
+            lib.emu_unit_stripe_rows(H, S, N, part, out.ctypes.data_as(C.c_void_p))
+            own = np.zeros(H, bool)
+            for a in range(part * S, H, S * N):
+                own[a:a + S] = True
+            need = own.copy()
+            for d in (1, 2):
+                need[:-d] |= own[d:]
+                need[d:] |= own[:-d]
+            assert np.array_equal(out > 0, need) and out.max() == 1, (H, S, N, part)
+            owned_all += own
+        assert (owned_all == 1).all()

@@ -471,3 +471,41 @@ def test_full_frame_config2_matches_oracle(render_schedule):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a != b).sum()} values differ"
     for which in (_abi.BUF_GBUF_DEPTH, _abi.BUF_GBUF_NORMAL, _abi.BUF_GBUF_MAT, _abi.BUF_HISTORY_DIFFUSE, _abi.BUF_HISTORY_SPECULAR):
         assert np.array_equal(g.fetch_buffer(which).view(np.uint8), o.fetch_buffer(which).view(np.uint8)), which
+
+
+def test_row_stripes_equal_full_frame():
+    """vrt_set_row_stripes: N whole-frame contexts, each producing every N-th stripe of S rows (SURVEY.md 8e's interleaved
+    partition).  Their rows put together -- through vrt_fetch_hdr (other rows zero) and through the compact device tile of
+    vrt_fetch_hdr_device -- are the unsharded frame bit for bit, after several fused and single-sample calls; odd heights and a
+    last stripe that is cut short included."""
+    import ctypes as C
+    mat, rgb, params = scenes.scene_sunlit(0)
+    for (W, H, S, N) in ((160, 100, 8, 3), (192, 136, 32, 2), (96, 72, 16, 5)):
+        cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=5, seed=17)
+        full = gpu_session(cfg)
+        orc.setup(full, mat, rgb, params)
+        calls = (4, 1, 3)
+        for n in calls:
+            full.accumulate(n)
+        want = full.fetch_hdr()
+        want_hist = full.fetch_buffer(_abi.BUF_HISTORY_DIFFUSE)
+        full.close()
+        got = np.zeros_like(want)
+        seen = np.zeros(H, int)
+        for part in range(N):
+            s = gpu_session(cfg)
+            s.set_row_stripes(S, N, part)
+            orc.setup(s, mat, rgb, params)
+            for n in calls:
+                s.accumulate(n)
+            rows = s.owned_rows()
+            seen[rows] += 1
+            hdr = s.fetch_hdr()
+            other = np.setdiff1d(np.arange(H), rows)
+            assert not hdr[other].any()
+            got[rows] = hdr[rows]
+            assert np.array_equal(s.fetch_buffer(_abi.BUF_HISTORY_DIFFUSE)[rows].view(np.uint32), want_hist[rows].view(np.uint32))
+            assert s.stats()["path_samples"] == len(rows) * W * sum(calls)
+            s.close()
+        assert (seen == 1).all()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (W, H, S, N)

@@ -36,6 +36,12 @@ CASES = [
     dict(name="shard_1of4_config4", scene="dense", W=3840, H=2160, depth=8, spp=4, steps=8, rows=(540, 1080)),
     dict(name="shard_1of8_config4", scene="dense", W=3840, H=2160, depth=8, spp=4, steps=12, rows=(1080, 1350)),
     dict(name="shard_1of8_config5", scene="dense256", W=3840, H=2160, depth=8, spp=4, steps=12, rows=(1080, 1350), grid=256),
+    # one rank's share of an 8-GPU run as INTERLEAVED STRIPES (vrt_set_row_stripes): part 3 of 8, stripes of 8 / 32 / 64 rows
+    dict(name="stripes8_1of8_config2", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=20, stripes=(8, 8, 3)),
+    dict(name="stripes32_1of8_config2", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=20, stripes=(32, 8, 3)),
+    dict(name="stripes64_1of8_config2", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=20, stripes=(64, 8, 3)),
+    dict(name="stripes32_1of8_config4", scene="dense", W=3840, H=2160, depth=8, spp=4, steps=12, stripes=(32, 8, 3)),
+    dict(name="stripes64_1of8_config4", scene="dense", W=3840, H=2160, depth=8, spp=4, steps=12, stripes=(64, 8, 3)),
     # the reference's own loop shape: one sample per call, a new jitter and vrt_end_frame every frame (scene.py:177, 233-262)
     dict(name="scene_api_default_1080p", scene="s1", W=1920, H=1080, depth=8, spp=1, steps=120, per_frame_camera=True),
 ]
@@ -52,6 +58,8 @@ def run(case):
     cfg = host.make_config(case["W"], case["H"], voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=case["depth"],
                            seed=0, use_restir=case.get("restir", False), sky_res=sky_res, rows=case.get("rows"), grid_res=case.get("grid", 128))
     s = NativeSession(lib, "vrt_", cfg)
+    if case.get("stripes"):
+        s.set_row_stripes(*case["stripes"])
     if os.environ.get("VRT_BENCH_RESERVE"):   # one GPU's cost of the workgroup slots a multi-GPU rank leaves to RCCL
         s.reserve_cus(int(os.environ["VRT_BENCH_RESERVE"]))
     s.upload_voxels(mat, rgb)
@@ -116,7 +124,8 @@ def run(case):
     n = ist["path_samples"]
     hdr = s.fetch_hdr()
     rows = case.get("rows") or (0, case["H"])
-    out = dict(name=case["name"], mpaths_per_s=round(case["W"] * (rows[1] - rows[0]) * case["spp"] * case["steps"] / dt / 1e6, 1),
+    n_rows = len(s.owned_rows()) if case.get("stripes") else rows[1] - rows[0]
+    out = dict(name=case["name"], mpaths_per_s=round(case["W"] * n_rows * case["spp"] * case["steps"] / dt / 1e6, 1), ms_per_step=round(dt / case["steps"] * 1e3, 4), rows=int(n_rows),
                render_ms=round(st["render_ms"] / max(st["render_launches"], 1), 3),
                gris_ms=round(st["gris_ms"] / max(st["gris_launches"], 1), 3),
                temporal_ms=round(st["temporal_ms"] / max(st["temporal_launches"], 1), 3),

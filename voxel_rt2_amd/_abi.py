@@ -93,3 +93,4 @@ def declare(lib, prefix):
     sig("last_error", C.c_char_p)
     sig("is_instrumented", C.c_int)
     sig("set_reference_indexing", C.c_int, P, C.c_int)
+    sig("set_row_stripes", C.c_int, P, C.c_int, C.c_int, C.c_int)

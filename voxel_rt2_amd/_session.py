@@ -95,6 +95,19 @@ class NativeSession:
         instead of "empty": include/vrt_api.h, vrt_set_reference_indexing."""
         self._call("set_reference_indexing", int(bool(on)))
 
+    def set_row_stripes(self, stripe_rows, n_parts, part):
+        """This (whole-frame) context produces every n_parts-th stripe of stripe_rows rows: include/vrt_api.h, vrt_set_row_stripes."""
+        self._call("set_row_stripes", int(stripe_rows), int(n_parts), int(part))
+        self.stripes = (int(stripe_rows), int(n_parts), int(part)) if stripe_rows else None
+
+    def owned_rows(self):
+        """Row indices this session produces, in the order its device tiles hold them."""
+        st = getattr(self, "stripes", None)
+        if not st:
+            return np.arange(self.rows[0], self.rows[1])
+        s_, n_, p_ = st
+        return np.concatenate([np.arange(a, min(a + s_, self.H)) for a in range(p_ * s_, self.H, s_ * n_)])
+
     # -- work ------------------------------------------------------------------------------
     def prepare(self):
         self._call("prepare")

@@ -102,6 +102,7 @@ struct vrt_ctx {
     PrimaryRecord* d_prim_cache[VRT_MAX_STREAMS] = {};  // camera-ray records of fused launches (one table per render stream)
     // rows
     int own0 = 0, own1 = 0;   // rows this context produces
+    int stripe_rows = 0, stripe_parts = 0, stripe_part = 0;   // ... or, of them, every stripe_parts-th stripe of stripe_rows rows (vrt_set_row_stripes)
     int buf0 = 0, buf1 = 0;   // rows held in the buffers (own + halo)
     int halo = 2;
     size_t npix = 0;          // (buf1 - buf0) * W
@@ -270,6 +271,20 @@ static void resolve_events(vrt_ctx* c) {
     c->pending.clear();
 }
 
+// The row ranges this context produces: one, or with vrt_set_row_stripes its stripes.
+static std::vector<std::pair<int, int>> owned_ranges(const vrt_ctx* c) {
+    std::vector<std::pair<int, int>> r;
+    if (c->stripe_rows == 0) { r.emplace_back(c->own0, c->own1); return r; }
+    const int period = c->stripe_rows * c->stripe_parts;
+    for (int s0 = c->stripe_part * c->stripe_rows; s0 < c->cfg.height; s0 += period)
+        r.emplace_back(s0, s0 + c->stripe_rows < c->cfg.height ? s0 + c->stripe_rows : c->cfg.height);
+    return r;
+}
+static size_t owned_rows(const vrt_ctx* c) {
+    size_t n = 0;
+    for (const auto& r : owned_ranges(c)) n += (size_t)(r.second - r.first);
+    return n;
+}
 static FrameParams make_frame_params(const vrt_ctx* c) {
     FrameParams fp;
     memset(&fp, 0, sizeof(fp));
@@ -303,6 +318,12 @@ static FrameParams make_frame_params(const vrt_ctx* c) {
     fp.max_depth = c->cfg.max_depth;
     fp.seed = c->cfg.seed;
     fp.frame = c->frame;
+    if (c->stripe_rows) {
+        fp.stripe_rows = c->stripe_rows;
+        fp.stripe_period = c->stripe_rows * c->stripe_parts;
+        fp.stripe_first = c->stripe_part * c->stripe_rows;
+        fp.stripe_tile_rows = (int)owned_ranges(c).size() * (c->stripe_rows / 8 + 2);
+    }
     return fp;
 }
 // launches that count the reference's work walk every ray, as the reference and the oracle do; VRT_CULL=0 for A/B runs
@@ -519,7 +540,7 @@ int vrt_set_scene(vrt_ctx* c, const vrt_scene_params* s) {
 int vrt_set_camera(vrt_ctx* c, const vrt_camera* cam) {
     if (!c || !cam) return fail(VRT_E_INVALID, "null argument");
     if (!(cam->render_scale > 0.0f) || cam->render_scale > 1.0f) return fail(VRT_E_INVALID, "render_scale must be in (0, 1]");
-    if (cam->camera_is_moving && (c->own0 != 0 || c->own1 != c->cfg.height))
+    if (cam->camera_is_moving && (c->own0 != 0 || c->own1 != c->cfg.height || c->stripe_rows))
         return fail(VRT_E_INVALID, "row-sharded contexts support the static camera only (history resampling crosses tiles)");
     c->cam = *cam;
     c->have_cam = true;
@@ -531,6 +552,17 @@ int vrt_reserve_cus(vrt_ctx* c, int n_cus) {
     HIP_TRY(hipSetDevice(c->device));
     c->reserved_cus = n_cus;
     c->render_blocks = 0;   // the grid is sized again at the next vrt_accumulate
+    return VRT_OK;
+}
+int vrt_set_row_stripes(vrt_ctx* c, int stripe_rows, int n_parts, int part) {
+    if (!c) return fail(VRT_E_INVALID, "null context");
+    if (stripe_rows == 0) { c->stripe_rows = c->stripe_parts = c->stripe_part = 0; return VRT_OK; }
+    if (stripe_rows < 8 || stripe_rows % 8 != 0 || n_parts < 1 || part < 0 || part >= n_parts) return fail(VRT_E_INVALID, "stripe_rows must be a multiple of 8, 0 <= part < n_parts");
+    if (c->own0 != 0 || c->own1 != c->cfg.height) return fail(VRT_E_INVALID, "row stripes are a property of a whole-frame context (row_begin = row_end = 0)");
+    if (c->cfg.use_restir) return fail(VRT_E_INVALID, "row stripes with ReSTIR would render a 24-row halo around every stripe: use contiguous row tiles");
+    if (c->have_cam && c->cam.camera_is_moving) return fail(VRT_E_INVALID, "row stripes support the static camera only");
+    if (c->frame != 0) return fail(VRT_E_STATE, "set the stripes before the first vrt_accumulate");
+    c->stripe_rows = stripe_rows; c->stripe_parts = n_parts; c->stripe_part = part;
     return VRT_OK;
 }
 int vrt_set_instrumented(vrt_ctx* c, int on) {
@@ -662,7 +694,7 @@ static bool ensure_overlap(vrt_ctx* c, int g) {   // g: samples of the launch th
     // the two-deep pipeline.
     // VRT_DEEP_ITEMS: largest launch (pixels x fused samples) that gets the deep pipeline; VRT_STREAMS / VRT_GRID_DIV override.
     const size_t deep_items = (size_t)c->knobs.deep_items;      // 12 M
-    const size_t items = (size_t)c->cfg.width * (size_t)(c->own1 - c->own0) * (size_t)g;
+    const size_t items = (size_t)c->cfg.width * owned_rows(c) * (size_t)g;
     const bool deep = items <= deep_items;
     // Deeper still for the smallest frames -- one rank's rows of an 8-GPU split of 1080p are 1 M items a launch: eight launches
     // of a quarter of the slots each (profiles/r02_pipeline_depth.txt: +7.5 % on those rows, +1 % on half a frame, nothing on a
@@ -953,12 +985,18 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             tb.hdr = c->d_cbuf[ci ^ 1];
             tb.sample_stride = restir ? 0 : out.sample_stride;
             tb.prev_view = c->prev_view; tb.prev_proj = c->prev_proj;
-            tb.tile = (done + g >= n_samples && s == passes - 1) ? next_hdr_target(c) : nullptr;   // the pass that completes the call
-            tb.tile_row0 = c->own0;
+            f3* const tile = (done + g >= n_samples && s == passes - 1) ? next_hdr_target(c) : nullptr;   // the pass that completes the call
             if (wait_cbuf_readers(c, ci ^ 1) != VRT_OK) return VRT_E_DEVICE;
             if (record(c, 1, &a, &b) != VRT_OK) return VRT_E_DEVICE;
             HIP_TRY(hipEventRecord(a, c->stream));
-            HIP_TRY(launch_temporal(c->stream, fps, tb, c->own0, c->own1, restir ? 1 : g));
+            tb.tile = tile;
+            tb.tile_row0 = c->own0;
+            if (c->stripe_rows) {   // one launch over the context's own rows, stripe after stripe (the kernel maps them: k_temporal)
+                const int n_own = (int)owned_ranges(c).size() * c->stripe_rows;   // (a last stripe cut short by the frame's edge is cut there)
+                HIP_TRY(launch_temporal(c->stream, fps, tb, 0, n_own, g));
+            } else {
+                HIP_TRY(launch_temporal(c->stream, fps, tb, c->own0, c->own1, restir ? 1 : g));
+            }
             HIP_TRY(hipEventRecord(b, c->stream));
             hist ^= 1; ci ^= 1;   // pathtracer.py:1298-1303 copy loop == pointer swaps, once per accumulation pass
         }
@@ -976,7 +1014,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         c->cur = (c->cur + 1) % VRT_GB_ROT;
         c->cidx = ci;
         c->frame += (uint32_t)g;
-        c->stats.path_samples += (uint64_t)g * (uint64_t)c->cfg.width * (uint64_t)(c->own1 - c->own0);
+        c->stats.path_samples += (uint64_t)g * (uint64_t)c->cfg.width * (uint64_t)owned_rows(c);
         done += g;
     }
     return VRT_OK;
@@ -1009,10 +1047,12 @@ int vrt_sync(vrt_ctx* c) {
 static int fetch_rows(vrt_ctx* c, const void* dbuf, size_t elem, void* out) {
     HIP_TRY(hipSetDevice(c->device));
     const size_t W = c->cfg.width;
-    if (c->own0 != 0 || c->own1 != c->cfg.height) memset(out, 0, (size_t)c->cfg.height * W * elem);   // a shard: the other rows are zero
-    const char* src = (const char*)dbuf + (size_t)(c->own0 - c->buf0) * W * elem;
-    char* dst = (char*)out + (size_t)c->own0 * W * elem;
-    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)(c->own1 - c->own0) * W * elem, hipMemcpyDeviceToHost, c->stream));
+    if (c->own0 != 0 || c->own1 != c->cfg.height || c->stripe_rows) memset(out, 0, (size_t)c->cfg.height * W * elem);   // a shard: the other rows are zero
+    for (const auto& rr : owned_ranges(c)) {
+        const char* src = (const char*)dbuf + (size_t)(rr.first - c->buf0) * W * elem;
+        char* dst = (char*)out + (size_t)rr.first * W * elem;
+        HIP_TRY(hipMemcpyAsync(dst, src, (size_t)(rr.second - rr.first) * W * elem, hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(sync_guarded(c, c->stream));
     return VRT_OK;
 }
@@ -1025,8 +1065,12 @@ int vrt_fetch_hdr_device(vrt_ctx* c, void* device_ptr) {
     if (!c || !device_ptr) return fail(VRT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     const size_t W = c->cfg.width;
-    const char* src = (const char*)c->d_cbuf[c->cidx] + (size_t)(c->own0 - c->buf0) * W * sizeof(f3);
-    HIP_TRY(hipMemcpyAsync(device_ptr, src, (size_t)(c->own1 - c->own0) * W * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
+    size_t done = 0;   // (a striped context's rows: one stripe after the other)
+    for (const auto& rr : owned_ranges(c)) {
+        const char* src = (const char*)c->d_cbuf[c->cidx] + (size_t)(rr.first - c->buf0) * W * sizeof(f3);
+        HIP_TRY(hipMemcpyAsync((char*)device_ptr + done * W * sizeof(f3), src, (size_t)(rr.second - rr.first) * W * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
+        done += (size_t)(rr.second - rr.first);
+    }
     HIP_TRY(sync_guarded(c, c->stream));
     return VRT_OK;
 }
@@ -1034,8 +1078,12 @@ int vrt_fetch_hdr_device_async(vrt_ctx* c, void* device_ptr) {
     if (!c || !device_ptr) return fail(VRT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     const size_t W = c->cfg.width;
-    const char* src = (const char*)c->d_cbuf[c->cidx] + (size_t)(c->own0 - c->buf0) * W * sizeof(f3);
-    HIP_TRY(hipMemcpyAsync(device_ptr, src, (size_t)(c->own1 - c->own0) * W * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
+    size_t done = 0;   // (a striped context's rows: one stripe after the other)
+    for (const auto& rr : owned_ranges(c)) {
+        const char* src = (const char*)c->d_cbuf[c->cidx] + (size_t)(rr.first - c->buf0) * W * sizeof(f3);
+        HIP_TRY(hipMemcpyAsync((char*)device_ptr + done * W * sizeof(f3), src, (size_t)(rr.second - rr.first) * W * sizeof(f3), hipMemcpyDeviceToDevice, c->stream));
+        done += (size_t)(rr.second - rr.first);
+    }
     return VRT_OK;
 }
 int vrt_set_stream(vrt_ctx* c, void* hip_stream) {
@@ -1083,6 +1131,7 @@ static int fetch_async(vrt_ctx* c, void* out, int slot, int what /* 0 HDR, 1 LDR
     if (!c || !out || slot < 0 || slot >= VRT_FETCH_SLOTS) return fail(VRT_E_INVALID, "bad argument (slot must be 0..3)");
     if (ldr && !c->have_cam) return fail(VRT_E_STATE, "vrt_set_camera has not been called");
     if (c->fetch_valid[slot]) return fail(VRT_E_STATE, "this slot's previous fetch has not been collected (vrt_fetch_wait)");
+    if (c->stripe_rows) return fail(VRT_E_STATE, "asynchronous fetches are not available on a context with row stripes");
     HIP_TRY(hipSetDevice(c->device));
     if (what == 2 && !c->d_ldr8 && dalloc(&c->d_ldr8, c->npix) != hipSuccess) { c->d_ldr8 = nullptr; return fail(VRT_E_DEVICE, "no memory for the 8-bit image"); }
     if (ensure_fetch_stream(c) != VRT_OK) return VRT_E_DEVICE;

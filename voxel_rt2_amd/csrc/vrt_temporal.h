@@ -40,9 +40,15 @@ struct TemporalBuffers {
     f3* tile;                     // or null: the caller's copy of the HDR rows [tile_row0, ...) (vrt_set_hdr_targets: the tile a
     int tile_row0;                // multi-GPU rank hands to the gather), written with the frame instead of copied afterwards
 };
+// STRIPED: a context with row stripes (vrt_set_row_stripes; a kernel of its own, so that the usual one carries none of this)
+template <bool STRIPED>
 VRT_DEV void store_hdr(const FrameParams& fp, const TemporalBuffers& tb, int idx, int u, int v, f3 c) {
     tb.hdr[idx] = c;
-    if (tb.tile) tb.tile[(v - tb.tile_row0) * fp.W + u] = c;
+    if (tb.tile) {   // the context's rows, one after the other (stripe after stripe on a striped context)
+        int row = v - tb.tile_row0;
+        if (STRIPED) { const int d = v - fp.stripe_first; row = (d / fp.stripe_period) * fp.stripe_rows + d % fp.stripe_period; }
+        tb.tile[row * fp.W + u] = c;
+    }
 }
 
 VRT_DEV f3 scrub(f3 c) {  // pathtracer.py:1069-1075
@@ -145,12 +151,13 @@ VRT_DEV void blend_history(const FrameParams& fp, float wsum, f4& h, f3 cur) {  
 // One pixel (u, v) of this shard's rows.  n_samples > 1: the samples of one accumulate(n) call, rendered by one
 // fused k_render launch into consecutive planes (static camera only): the running means are advanced n times in
 // registers, in sample order, exactly as n separate passes would, and the histories / HDR are written once.
+template <bool STRIPED = false>
 VRT_DEV void temporal_pixel(const FrameParams& fp, const TemporalBuffers& tb, int u, int v, int n_samples) {
     const int idx = (v - fp.row0) * fp.W + u;
     if (outside_render_area(fp, (float)u, (float)v)) {
         // not rendered at this render_scale: the reference leaves color_buffer (= the last HDR value) untouched.
         // The render target and the HDR target swap roles every pass, so carry the value across.
-        store_hdr(fp, tb, idx, u, v, tb.color_d[idx]);
+        store_hdr<STRIPED>(fp, tb, idx, u, v, tb.color_d[idx]);
         tb.hist_d_out[idx] = tb.hist_d_in[idx];
         tb.hist_s_out[idx] = tb.hist_s_in[idx];
         return;
@@ -176,7 +183,7 @@ VRT_DEV void temporal_pixel(const FrameParams& fp, const TemporalBuffers& tb, in
     const float nl_depth = tb.gb_depth[idx];
     const f3 x1 = xform(fp.view_inv, screen_to_view(tc, nl_depth, fp.proj_inv), 1.0f);
     if (near_zero3(x1)) {  // both filters `continue`: colour stays the scrubbed diffuse sample, histories persist
-        store_hdr(fp, tb, idx, u, v, scrub(tb.color_d[last + idx]));
+        store_hdr<STRIPED>(fp, tb, idx, u, v, scrub(tb.color_d[last + idx]));
         tb.hist_d_out[idx] = tb.hist_d_in[idx];
         tb.hist_s_out[idx] = tb.hist_s_in[idx];
         return;
@@ -208,7 +215,7 @@ VRT_DEV void temporal_pixel(const FrameParams& fp, const TemporalBuffers& tb, in
     tb.hist_s_out[idx] = hs;
     f3 col = mk3(hd.x, hd.y, hd.z);
     if (fp.camera_is_moving == 1) col = col * unpack_albedo(tb.gb_mat[idx]);  // re-modulate albedo (:1227-1228)
-    store_hdr(fp, tb, idx, u, v, col + mk3(hs.x, hs.y, hs.z));
+    store_hdr<STRIPED>(fp, tb, idx, u, v, col + mk3(hs.x, hs.y, hs.z));
 }
 
 // Renderer._render_to_image (pathtracer.py:634-662) with uchimura (math_utils.py:163-186)

@@ -175,6 +175,10 @@ struct FrameParams {
     f2 inv_res;
     int W, H;
     int row0, row1;             // rows rendered by this launch (shard + halo)
+    // Interleaved row stripes (vrt_set_row_stripes; 0 = off): of every stripe_period rows this launch renders the stripe_rows rows
+    // from stripe_first on, plus two rows either side (what the temporal pass reads of its neighbours).  stripe_tile_rows: 8-row
+    // tile rows the launch enumerates -- per stripe its own stripe_rows / 8 and one above and below for the halo rows.
+    int stripe_rows, stripe_period, stripe_first, stripe_tile_rows;
     int camera_is_moving;
     float render_scale, max_accum_frames;
     f3 light_dir, light_color;
@@ -188,6 +192,20 @@ struct FrameParams {
     int max_depth;
     uint32_t seed, frame;
 };
+
+// First image row of the launch's t-th 8-row tile row, and whether row v is one the launch renders (always, without stripes).
+VRT_DEV int launch_tile_row(const FrameParams& fp, int t) {
+    if (fp.stripe_period == 0) return fp.row0 + t * 8;
+    const int per = fp.stripe_rows / 8 + 2, k = t / per, j = t - k * per;
+    return k * fp.stripe_period + fp.stripe_first - 8 + j * 8;
+}
+VRT_DEV int launch_tile_rows(const FrameParams& fp) { return fp.stripe_period == 0 ? (fp.row1 - fp.row0 + 7) >> 3 : fp.stripe_tile_rows; }
+VRT_DEV bool launch_renders_row(const FrameParams& fp, int v) {
+    if (fp.stripe_period == 0) return true;
+    if (v < fp.row0) return false;
+    const int m = (v - fp.stripe_first + 2 + fp.stripe_period) % fp.stripe_period;   // (v >= 0 > stripe_first - 2 - period)
+    return m < fp.stripe_rows + 4;
+}
 
 }  // namespace vrt
 #endif
