@@ -215,6 +215,10 @@ struct LdsPyramid2<256, CULL_, SHBR_, OOB_> {
 };
 template <int G> struct PoolGeom { static constexpr int waves = VRT_POOL_WAVES; };   // waves (= path pools) per workgroup
 template <> struct PoolGeom<256> { static constexpr int waves = 8; };
+#ifndef VRT_POOL_SLOTS_128
+#define VRT_POOL_SLOTS_128 VRT_POOL_SLOTS   // (experiments: another pool size at 128^3 only -- the 256^3 workgroup has no LDS to spare)
+#endif
+template <int G> struct PoolSlots { static constexpr int value = G == 256 ? VRT_POOL_SLOTS : VRT_POOL_SLOTS_128; };
 
 __device__ __forceinline__ void flush_stats(const TraceStats& ts, Counters* c) {
     // wave-level sum, one atomic per counter per wave
@@ -340,7 +344,7 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {  // set bits of
 // WAVES path pools of SLOTS slots per workgroup: 4 x 128 with two workgroups per CU (two waves per SIMD) by default; the whole l1
 // level of a 256^3 grid leaves room for one workgroup of 8 x 128 per CU; a DENSE 128^3 grid runs one workgroup of 12 x 96 per CU
 // -- three waves per SIMD at 168 registers (k_render_pool_dense12 below).
-template <int G, bool RESTIR, bool INSTR, bool BLACK_SUN, bool CULL, bool SHBR = false, int WAVES = PoolGeom<G>::waves, int SLOTS = VRT_POOL_SLOTS>
+template <int G, bool RESTIR, bool INSTR, bool BLACK_SUN, bool CULL, bool SHBR = false, int WAVES = PoolGeom<G>::waves, int SLOTS = PoolSlots<G>::value>
 // 208 registers per wave (the attribute counts half of the unified file): two waves per SIMD then leave the 96 that
 // k_temporal runs in beside them (see there).  The allocator would take 238; the cap costs 28 bytes of scratch.
 // The ReSTIR instantiation (no overlapped launches, so nothing runs beside it) takes the two-wave maximum of 256.
@@ -718,12 +722,15 @@ __global__ __launch_bounds__(256, (PHASE == 1 ? VRT_GRIS_MIN_WAVES_A : PHASE == 
 // LDS, the wave evaluates the list 64 at a time (a lane loads the sample of whichever pixel its item belongs to: 224 bytes from
 // L2 instead of registers kept across a loop) and leaves each term where the item was; then every lane sums ITS pixel's terms in
 // tap order, constants included -- the float sum of gris_pixel<1>, term for term (gris_first_term is the loop's body).
+#ifndef VRT_GRIS_FIRST_ROUNDS
+#define VRT_GRIS_FIRST_ROUNDS 1
+#endif
 template <int G, bool INSTR>
 __global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES_A) void k_gris_first(FrameParams fp, SceneData sc, GrisBuffers gb, int r0, int r_first, int r1, int tiles_x, int band_w) {
     __shared__ float s_mats[128 * 14];
     __shared__ float s_mats_x[128 * 8];
     __shared__ float s_cs[4][64];          // per wave (= 8x8 pixel tile): cos / sin of the 32 tap angles
-    __shared__ uint32_t s_item[4][64 * 32];  // per wave: (lane << 8 | tap) of every tap to evaluate, then the tap's term in its place
+    __shared__ uint32_t s_item[4][64 * 32 / VRT_GRIS_FIRST_ROUNDS];  // per wave: (lane << 8 | tap) of every tap to evaluate, then the tap's term in its place
     __shared__ float s_radius[4][64];      // per wave: each pixel's radius_shift
     for (int i = threadIdx.x; i < 128 * 14; i += blockDim.x) s_mats[i] = sc.mats[i];
     for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) s_mats_x[i] = gb.mats_x[i];
@@ -765,44 +772,51 @@ __global__ __launch_bounds__(256, VRT_GRIS_MIN_WAVES_A) void k_gris_first(FrameP
             const_term = gris_first_const_term(c, max_taps);
         }
     }
-    // where this lane's items start in the wave's list: exclusive prefix sum of the counts
-    const int cnt = __builtin_popcount(walk);
-    int incl = cnt;
-    for (int off = 1; off < 64; off <<= 1) {
-        const int up = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += up;
-    }
-    const int base = incl - cnt;
-    const int total = __shfl(incl, 63, 64);
-    {
-        int k = base;
-        for (unsigned m = walk; m != 0u; m &= m - 1u) item[k++] = ((uint32_t)lane << 8) | (uint32_t)__builtin_ctz(m);
-    }
-    wave_lds_sync();
-    for (int k0 = 0; k0 < total; k0 += 64) {
-        const int k = k0 + lane;
-        if (k < total) {
-            const uint32_t e = item[k];
-            const int q = (int)(e >> 8), i = (int)(e & 31u);
-            const int uq = u0 + (q & 7), vq = v0 + (q >> 3);
-            int tx, ty;
-            (void)gris_tap(fp, taps, uq, vq, i, s_radius[wave][q], max_radius, max_taps, tx, ty);
-            Reservoir center;
-            f3 center_rc_ty, center_sky_t;
-            RcPre center_pre;
-            gris_load_src(center, center_rc_ty, center_sky_t, center_pre, gb.src[(vq - fp.row0) * fp.W + uq]);
-            item[k] = dm_f2u(gris_first_term(fp, scl, gbl, center, center_rc_ty, center_sky_t, center_pre, tx, ty, max_taps, ts));
+    // Two rounds, the pixels of lanes 0-31 and then of lanes 32-63 (VRT_GRIS_FIRST_ROUNDS = 2: a list of 32 x 32 entries per wave
+    // -- 16 KB per workgroup instead of 32 -- so that LDS leaves room for more waves per SIMD; 1: the whole wave's pixels at once).
+    float canonical_mis = 1.0f;
+    constexpr int ROUNDS = VRT_GRIS_FIRST_ROUNDS, PER = 64 / ROUNDS;
+    for (int round = 0; round < ROUNDS; round++) {
+        const bool in_round = lane / PER == round;
+        // where this lane's items start in the wave's list: exclusive prefix sum of the counts
+        const int cnt = in_round ? __builtin_popcount(walk) : 0;
+        int incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
         }
-    }
-    wave_lds_sync();
-    if (mine) {
-        float canonical_mis = 1.0f;
-        int k = base;
-        for (unsigned m = accepted; m != 0u; m &= m - 1u) {
-            const int i = __builtin_ctz(m);
-            canonical_mis += ((walk >> i) & 1u) ? dm_u2f(item[k++]) : const_term;
+        const int base = incl - cnt;
+        const int total = __shfl(incl, 63, 64);
+        if (in_round) {
+            int k = base;
+            for (unsigned m = walk; m != 0u; m &= m - 1u) item[k++] = ((uint32_t)lane << 8) | (uint32_t)__builtin_ctz(m);
         }
-        gb.geo[idx].pad3 = dm_f2u(canonical_mis);
+        wave_lds_sync();
+        for (int k0 = 0; k0 < total; k0 += 64) {
+            const int k = k0 + lane;
+            if (k < total) {
+                const uint32_t e = item[k];
+                const int q = (int)(e >> 8), i = (int)(e & 31u);
+                const int uq = u0 + (q & 7), vq = v0 + (q >> 3);
+                int tx, ty;
+                (void)gris_tap(fp, taps, uq, vq, i, s_radius[wave][q], max_radius, max_taps, tx, ty);
+                Reservoir center;
+                f3 center_rc_ty, center_sky_t;
+                RcPre center_pre;
+                gris_load_src(center, center_rc_ty, center_sky_t, center_pre, gb.src[(vq - fp.row0) * fp.W + uq]);
+                item[k] = dm_f2u(gris_first_term(fp, scl, gbl, center, center_rc_ty, center_sky_t, center_pre, tx, ty, max_taps, ts));
+            }
+        }
+        wave_lds_sync();
+        if (mine && in_round) {
+            int k = base;
+            for (unsigned m = accepted; m != 0u; m &= m - 1u) {
+                const int i = __builtin_ctz(m);
+                canonical_mis += ((walk >> i) & 1u) ? dm_u2f(item[k++]) : const_term;
+            }
+            gb.geo[idx].pad3 = dm_f2u(canonical_mis);
+        }
+        wave_lds_sync();   // (the list is written again by the next round)
     }
     if (INSTR) flush_stats(ts, sc.counters);
 }
@@ -987,7 +1001,7 @@ hipError_t query_render_pool_residency(int grid_res, bool restir, bool instr, in
 }
 size_t pool_scratch_bytes(int grid_res, bool restir, int n_blocks, int n_blocks_dense12) {   // room for either geometry
     const size_t line = (size_t)(restir ? ColdLine<true>::count : ColdLine<false>::count) * sizeof(uint32_t);
-    const size_t a = (size_t)n_blocks * pool_waves_per_block(grid_res) * VRT_POOL_SLOTS * line;
+    const size_t a = (size_t)n_blocks * pool_waves_per_block(grid_res) * (grid_res == 256 ? PoolSlots<256>::value : PoolSlots<128>::value) * line;
     const size_t b = (size_t)n_blocks_dense12 * VRT_D12_WAVES * VRT_D12_SLOTS * line;
     return a > b ? a : b;
 }
