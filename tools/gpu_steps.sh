@@ -10,6 +10,7 @@
 #   refidx          tools/ref_indexing_diff.py on configs 4 and 5 (GPU)
 #   trace:CASE      rocprofv3 --kernel-trace --stats of bench_scenes.py CASE (CASE = bench: the bench command, config 2)
 #   pmc:CASE        tools/pmc.sh CASE + summary
+#   traffic         counters of every config -> profiles/traffic.json for this build;  present: present rates;  pmcdefault: the default schedule under --pmc
 #   diag:NAME:ARGS       tools/diag_regions.py ARGS (comma separated) with build_variants/libvrt_NAME.so (a -DVRT_DIAG_REGIONS build)
 #   variant:NAME:CASES   tools/bench_scenes.py CASES (comma separated) with build_variants/libvrt_NAME.so (built beforehand: tools/build_variant.sh)
 set -o pipefail
@@ -55,6 +56,26 @@ for l in open('$O/scenes${arg:+_}${arg//,/_}.jsonl'):
 import json
 for l in open('$O/variant_$vname.jsonl'):
     d=json.loads(l); print('  [$vname]', d.get('name'), d.get('mpaths_per_s'), {k:v for k,v in d.items() if k.endswith('_ms')})" ;;
+    traffic)   # counters per config (tools/pmc.sh) -> profiles/traffic.json stamped with the build id; comes back as gpurun_out/TAG/traffic.json
+      python -c "from voxel_rt2_amd import _lib; print(_lib.build_id())" > $O/build_id.txt 2>/dev/null
+      ID=$(cat $O/build_id.txt); echo "build $ID"
+      for c in config2_s1 config5_dense256 config4_dense config3_s6; do
+        bash tools/pmc.sh $c ${TAG}_pmc_$c > /dev/null 2>&1 || fail traffic:$c $?
+        python tools/pmc_summary.py $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$c > $O/pmc_$c.txt
+        echo "pmc $c: $(grep -c mean $O/pmc_$c.txt) rows"
+      done
+      python tools/make_traffic.py $ID "$TAG" config2_s1_1080p=gpurun_out/${TAG}_pmc_config2_s1 config5_dense256_4k=gpurun_out/${TAG}_pmc_config5_dense256 \
+          config4_dense_4k=gpurun_out/${TAG}_pmc_config4_dense config3_s6_sky_clouds_restir_1080p=gpurun_out/${TAG}_pmc_config3_s6 > $O/traffic_digest.json || fail traffic 1
+      cp profiles/traffic.json $O/traffic.json
+      rm -rf gpurun_out/${TAG}_pmc_* ;;
+    present)   # the frame copied to the host after every step: blocking, asynchronous f32, asynchronous 8 bit
+      for mode in 1 async async8; do for lag in 1 2; do
+        [ $mode == 1 ] && [ $lag == 2 ] && continue
+        VRT_BENCH_STEPS=40 VRT_BENCH_FETCH_EACH=$mode VRT_BENCH_FETCH_LAG=$lag timeout -k 10 300 python tools/bench_scenes.py config2_s1 config4_dense 2>/dev/null | sed "s/_d8\"/_d8_present_${mode}_lag${lag}\"/; s/_1gpu\"/_1gpu_present_${mode}_lag${lag}\"/" >> $O/present.jsonl
+      done; done; echo "present: $(grep -c name $O/present.jsonl)" ;;
+    pmcdefault)
+      ( cd /tmp; export TMPDIR=/tmp; timeout -k 10 120 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU --output-format csv -d $O/pmc_default -o p -- python $GRAFT_REPO_ROOT/tools/probe_overlap.py > $O/pmc_default_schedule.txt 2>&1 ) || fail pmcdefault $?
+      rm -rf $O/pmc_default; tail -2 $O/pmc_default_schedule.txt ;;
     diag)   # diag:NAME:ARGS -> tools/diag_regions.py ARGS with build_variants/libvrt_NAME.so (a -DVRT_DIAG_REGIONS build)
       IFS=: read -r vname dargs <<< "$arg"
       VRT_LIB_PATH=$GRAFT_REPO_ROOT/build_variants/libvrt_$vname.so timeout -k 10 600 python tools/diag_regions.py ${dargs//,/ } > $O/diag_$vname.txt 2> $O/diag_$vname.err || { tail -5 $O/diag_$vname.err; fail diag:$vname $?; }

@@ -61,14 +61,19 @@ def main():
                                   ("k_render", "vrt::k_render<", 2), ("k_gris", "vrt::k_gris<", 1),
                                   ("k_gris_prepare", "vrt::k_gris_prepare", None), ("k_temporal", "vrt::k_temporal", None)):
             k, v = pick(m, prefix, ia)
-            if not v and short == "k_render_pool":   # the dense-grid variant of the same kernel (k_render_pool_dense<G, INSTR, CULL>)
-                k, v = pick(m, "vrt::k_render_pool_dense<", 1)
+            if not v and short == "k_render_pool":   # the dense-grid variants of the same kernel (k_render_pool_dense12 / _dense<G, INSTR, CULL>)
+                k, v = pick(m, "vrt::k_render_pool_dense12<", 1)
+                if not v:
+                    k, v = pick(m, "vrt::k_render_pool_dense<", 1)
             if v and short == "k_gris":
                 # the spatial-reuse pass runs as two kernels (template argument 3 = 1, 2: vrt_restir.h): one entry, their counters summed
                 # (round 3: behind a third, k_gris_classify<INSTR>, that hands them their masks of accepted and of live taps)
                 halves = [(kk, vv) for kk, vv in m.items() if kk.replace("void ", "").startswith(prefix)
                           and [a_.strip() for a_ in kk.split("<")[1].rstrip(">").split(",")][ia] != "true"]
                 halves += [(kk, vv) for kk, vv in m.items() if kk.replace("void ", "").startswith("vrt::k_gris_classify<false>")]
+                # round 4: the first of the two is k_gris_first<G, INSTR> (wave-level schedule), and the per-pixel records' pass counts too
+                halves += [(kk, vv) for kk, vv in m.items() if kk.replace("void ", "").startswith("vrt::k_gris_first<") and kk.rstrip(">").endswith("false")]
+                halves += [(kk, vv) for kk, vv in m.items() if kk.replace("void ", "").startswith("vrt::k_gris_prepare")]
                 if len(halves) > 1:
                     names = sorted(kk for kk, _ in halves)
                     summed = {}
