@@ -109,6 +109,8 @@ class Renderer(VoxelStore):
                                device=device, rows=rows, dx=dx,
                                grid_res=int(os.environ.get("VRT_GRID_RES", 128)) if grid_res is None else int(grid_res))
         self._s = NativeSession(_lib.load(), "vrt_", cfg)   # the library insists on dx == 2 / grid_res
+        if int(os.environ.get("VRT_REFERENCE_INDEXING", 0)):
+            self._s.set_reference_indexing(True)
 
         # voxel storage the user kernels write through set_voxel (voxel_world.py:7-18)
         self._init_voxels(cfg.grid_res)
@@ -230,6 +232,11 @@ class Renderer(VoxelStore):
 
     def fetch_hdr(self):
         return self._s.fetch_hdr()
+
+    def set_reference_indexing(self, on=True):
+        """Occupancy queries outside the grid read the bit the reference's index arithmetic addresses (raytracer.py:17-38)
+        instead of "empty" (the default).  Also `VRT_REFERENCE_INDEXING=1` in the environment."""
+        self._s.set_reference_indexing(on)
 
     # The reference shows every frame (scene.py:255-262: accumulate, fetch_image, canvas.set_image).  A blocking fetch_image
     # waits for every launch queued so far; these two queue the tonemap and the copy of an 8-bit image behind the frame and
