@@ -503,7 +503,7 @@ def main():
             "config": {"workload": "example1-style scene S1 (scenes.scene_s1), 128^3 grid, 1920x1080, 4 spp/step, 8 bounces, "
                                    "static camera, ReSTIR off", "width": WIDTH, "height": HEIGHT, "spp_per_step": SPP_PER_STEP,
                        "max_depth": MAX_DEPTH, "seed": SEED, "build_id": lib.vrt_build_id().decode(),
-                       "launch_pipeline": {"overlapped": bool(flags & 1), "dispatch_gate": bool(flags & 2), "gate_host_releases": int(flags >> 8),
+                       "launch_pipeline": {"overlapped": bool(flags & 1), "dispatch_gate": bool(flags & 2), "gate_host_releases": int((flags >> 8) & 0xFFFF),
                                            "launches_in_flight": 2 * int((flags >> 2) & 7), "workgroup_slots_per_launch": f"1/{max(int((flags >> 5) & 7), 1)}"},
                        "sharding": ((f"{world} sets of interleaved {stripes}-row stripes (every rank renders row stripes spread over the whole frame, two more rows either side of each), "
                                      if stripes else f"{world} contiguous row tiles, boundaries balanced by measured tile cost, ") + "HDR tile written by the temporal pass into a ring "

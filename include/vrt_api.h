@@ -93,7 +93,9 @@ typedef struct vrt_stats {
                                      where a self-test finds that queue operations are serialised, e.g. under rocprofv3 --pmc);
                                      bits 2..4: HALF the render launches the pipeline keeps in flight (1, 2, 4 for 2, 4, 8; 0 while not overlapped);
                                      bits 5..7: a launch takes 1 / this many of the workgroup slots (1, 2 or 4);
-                                     bits 8..31: times the host released that wait (error paths, synchronisation watchdog) */
+                                     bits 8..23: times the host released that wait (error paths, synchronisation watchdog);
+                                     bits 24..31: times the pipeline was drained to change its depth (a caller that changes the
+                                     sample count of its calls: the depth follows the launch size) */
 } vrt_stats;
 
 /* buffers readable through vrt_fetch_buffer (tests and the multi-GPU gather) */

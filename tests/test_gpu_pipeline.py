@@ -50,7 +50,7 @@ def reference_frame():
 def test_overlapped_launches_with_gate(reference_frame, monkeypatch):
     hdr, st = render()
     assert st["pipeline_flags"] & 3 == 3, "overlapped launches with the dispatch gate are the default on a plain GPU box"
-    assert st["pipeline_flags"] >> 8 <= 1   # only the release at context teardown may have happened
+    assert (st["pipeline_flags"] >> 8) & 0xFFFF <= 1   # only the release at context teardown may have happened
     assert np.array_equal(hdr.view(np.uint32), reference_frame.view(np.uint32))
 
 
@@ -76,7 +76,7 @@ def test_host_release_of_the_gate_changes_nothing(reference_frame, monkeypatch):
         s.sync()
     hdr, st = s.fetch_hdr(), s.stats()
     s.close()
-    assert st["pipeline_flags"] >> 8 >= 2
+    assert (st["pipeline_flags"] >> 8) & 0xFFFF >= 2
     assert np.array_equal(hdr.view(np.uint32), reference_frame.view(np.uint32))
 
 
@@ -188,7 +188,7 @@ def test_accumulate_failure_rolls_back(monkeypatch):
     assert lib.vrt_accumulate(C.c_void_p(s._ctx), 4) == -2 and b"injected" in lib.vrt_last_error()
     assert lib.vrt_accumulate(C.c_void_p(s._ctx), -1) == -1
     s.accumulate(4)
-    assert s.stats()["pipeline_flags"] >> 8 >= 1   # the failed launch's gate was released from the host
+    assert (s.stats()["pipeline_flags"] >> 8) & 0xFFFF >= 1   # the failed launch's gate was released from the host
     assert np.array_equal(s.fetch_hdr().view(np.uint32), want.view(np.uint32))
     s.close()
 
@@ -197,6 +197,49 @@ def _session(cfg, mat, rgb, params, cam=None):
     s = NativeSession(_lib.load(), "vrt_", cfg)
     orc.setup(s, mat, rgb, params, cam=cam)
     return s
+
+
+def test_pipeline_depth_follows_the_launch_size(monkeypatch):
+    """A caller that changes the sample count of its calls: the depth of the pipeline follows the size of each launch (the
+    pipeline is drained once per change), whatever the first call was.  Development build with the size limits moved so that
+    this small frame has launches of all three kinds: one sample -> eight launches of a quarter of the slots, two -> four of a
+    half, three or four -> two of every slot."""
+    calls = (1, 4, 4, 2, 1, 1, 3, 4, 2, 2, 1) * 2
+    monkeypatch.setenv("VRT_OVERLAP", "0")
+    ref, st = render(calls)
+    assert st["pipeline_flags"] & 1 == 0
+    monkeypatch.delenv("VRT_OVERLAP")
+    monkeypatch.setenv("VRT_DEEPER_ITEMS", str(W * H + 1))
+    monkeypatch.setenv("VRT_DEEP_ITEMS", str(2 * W * H + 1))
+    hdr, st = render(calls, dev=True)
+    switches = st["pipeline_flags"] >> 24
+    assert st["pipeline_flags"] & 1 == 1 and switches >= 12, st
+    assert (st["pipeline_flags"] >> 2) & 7 == 4 and (st["pipeline_flags"] >> 5) & 7 == 4, "the last call was one sample: eight launches of a quarter"
+    assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32))
+
+
+def test_pipeline_depth_of_the_shipped_library_at_720p(monkeypatch):
+    """The shipped library's own limits: at 1280x720 a one-sample call is a small launch (0.9 M items: eight deep), a four-sample
+    call a middle one (3.7 M: four deep).  (1, 4, 4, 1, 1, 4): three changes of depth, the frame that of isolated launches."""
+    mat, rgb, params = scenes.scene_sunlit(0)
+    cfg = host.make_config(1280, 720, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=DEPTH, seed=5)
+    frames = []
+    for overlap in ("0", None):
+        if overlap is not None:
+            monkeypatch.setenv("VRT_OVERLAP", overlap)
+        else:
+            monkeypatch.delenv("VRT_OVERLAP")
+        s = _session(cfg, mat, rgb, params)
+        for n in (1, 4, 4, 1, 1, 4):
+            s.accumulate(n)
+        frames.append((s.fetch_hdr(), s.stats()))
+        s.close()
+    (ref, st0), (hdr, st) = frames
+    assert st0["pipeline_flags"] & 1 == 0 and st["pipeline_flags"] & 1 == 1
+    if os.environ.get("GPU_MAX_HW_QUEUES") == "16":   # (the eight-deep pipeline needs sixteen hardware queues: _lib.load asks for them)
+        assert st["pipeline_flags"] >> 24 == 3, st
+        assert (st["pipeline_flags"] >> 2) & 7 == 2, "the last call was four samples: four launches of half the slots"
+    assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32))
 
 
 def test_single_sample_calls_with_a_new_jitter_each():

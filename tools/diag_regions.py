@@ -53,20 +53,36 @@ if len(sys.argv) > 1 and sys.argv[1] == "gris":
         gris(scene)
     sys.exit(0)
 for scene in sys.argv[1:] or ["s1", "sunlit", "dense"]:
+    # NAME or NAME@row0:row1 (a rank's rows of a multi-GPU split) or NAME@row0:row1xK (K calls queued together, the pipeline in flight)
+    rows, calls, stripes = None, 1, None     # NAME@S32/8/3[xK]: rank 3's share of 8 in stripes of 32 rows
+    if "@" in scene:
+        scene, r = scene.split("@")
+        if "x" in r:
+            r, k = r.split("x"); calls = int(k)
+        if r.startswith("S"):
+            stripes = tuple(int(x) for x in r[1:].split("/"))
+        else:
+            rows = tuple(int(x) for x in r.split(":"))
     mat, rgb, params = scenes.SCENES[scene](12345 if scene == "dense" else 0)
     params = dict(params, use_physical_sky=0, use_clouds=0)
     W, H = 1920, 1080
-    cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=8, seed=0)
+    cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=8, seed=0, rows=rows)
     s = NativeSession(lib, "vrt_", cfg)
+    if stripes:
+        s.set_row_stripes(*stripes)
     s.upload_voxels(mat, rgb); s.upload_materials(materials.load_table())
     s.set_scene(host.make_scene_params(**params)); s.set_camera(host.default_camera(W, H, jitter_index=1)); s.prepare()
     out = np.zeros(64, dtype=np.uint64)
-    s.accumulate(4); s.sync()
+    for _ in range(max(calls, 2)):
+        s.accumulate(4)
+    s.sync()
     lib.vrt_diag_regions(C.c_void_p(s._ctx), out.ctypes.data_as(C.c_void_p), 1)
-    s.accumulate(4); s.sync()
+    for _ in range(calls):
+        s.accumulate(4)
+    s.sync()
     assert lib.vrt_diag_regions(C.c_void_p(s._ctx), out.ctypes.data_as(C.c_void_p), 1) == 0
-    n = W * H * 4
-    print(f"== {scene}: per path-sample")
+    n = W * (len(s.owned_rows()) if stripes else (rows[1] - rows[0]) if rows else H) * 4 * calls
+    print(f"== {scene}{'' if not stripes else f' stripes {stripes}'}{'' if not rows else f' rows {rows[0]}-{rows[1]}'}{'' if calls == 1 else f', {calls} calls queued together'}: per path-sample")
     for rid, name in sorted(NAMES.items()):
         ent, lanes = int(out[2 * rid]), int(out[2 * rid + 1])
         if ent:
@@ -74,6 +90,7 @@ for scene in sys.argv[1:] or ["s1", "sunlit", "dense"]:
     cyc = {k: int(out[2 * (20 + k)]) for k in range(6)}
     if sum(cyc.values()):
         tot = sum(cyc.values())
+        print(f"  pool wave-cycles per path-sample: {tot / n:.1f}")
         print("  pool wave-cycles by stage: " + "  ".join(f"{nm} {100 * cyc[k] / tot:.1f}%" for k, nm in
               ((0, "BEGIN"), (1, "WALK"), (2, "SHADE"), (3, "ESCAPE"), (5, "census"), (4, "start/exit"))))
     sub = [int(out[52 + k]) for k in range(4)]

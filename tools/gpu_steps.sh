@@ -10,6 +10,7 @@
 #   refidx          tools/ref_indexing_diff.py on configs 4 and 5 (GPU)
 #   trace:CASE      rocprofv3 --kernel-trace --stats of bench_scenes.py CASE (CASE = bench: the bench command, config 2)
 #   pmc:CASE        tools/pmc.sh CASE + summary
+#   timeline:CASE[:MODE[:LAG]]  launches and copies in time (tools/timeline.py)
 #   traffic         counters of every config -> profiles/traffic.json for this build;  present: present rates;  pmcdefault: the default schedule under --pmc
 #   diag:NAME:ARGS       tools/diag_regions.py ARGS (comma separated) with build_variants/libvrt_NAME.so (a -DVRT_DIAG_REGIONS build)
 #   variant:NAME:CASES   tools/bench_scenes.py CASES (comma separated) with build_variants/libvrt_NAME.so (built beforehand: tools/build_variant.sh)
@@ -71,8 +72,14 @@ for l in open('$O/variant_$vname.jsonl'):
     present)   # the frame copied to the host after every step: blocking, asynchronous f32, asynchronous 8 bit
       for mode in 1 async async8; do for lag in 1 2; do
         [ $mode == 1 ] && [ $lag == 2 ] && continue
-        VRT_BENCH_STEPS=40 VRT_BENCH_FETCH_EACH=$mode VRT_BENCH_FETCH_LAG=$lag timeout -k 10 300 python tools/bench_scenes.py config2_s1 config4_dense 2>/dev/null | sed "s/_d8\"/_d8_present_${mode}_lag${lag}\"/; s/_1gpu\"/_1gpu_present_${mode}_lag${lag}\"/" >> $O/present.jsonl
+        VRT_BENCH_STEPS=120 VRT_BENCH_FETCH_EACH=$mode VRT_BENCH_FETCH_LAG=$lag timeout -k 10 300 python tools/bench_scenes.py config2_s1 config4_dense 2>/dev/null | sed "s/_d8\"/_d8_present_${mode}_lag${lag}\"/; s/_1gpu\"/_1gpu_present_${mode}_lag${lag}\"/" >> $O/present.jsonl
       done; done; echo "present: $(grep -c name $O/present.jsonl)" ;;
+    timeline)   # timeline:CASE[:MODE[:LAG]] -> kernel + copy trace of tools/bench_scenes.py CASE (MODE: VRT_BENCH_FETCH_EACH), digested by tools/timeline.py
+      IFS=: read -r tcase tmode tlag <<< "$arg"
+      ( cd /tmp; export TMPDIR=/tmp VRT_BENCH_STEPS=60 VRT_BENCH_FETCH_EACH=$tmode VRT_BENCH_FETCH_LAG=${tlag:-1}
+        timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/tl_$tcase$tmode -o t -- python $GRAFT_REPO_ROOT/tools/bench_scenes.py $tcase > $O/tl_$tcase$tmode.jsonl 2> $O/tl_$tcase$tmode.err ) || fail timeline:$arg $?
+      python tools/timeline.py $O/tl_$tcase$tmode > $O/timeline_$tcase${tmode:+_}$tmode${tlag:+_lag}$tlag.txt; rm -rf $O/tl_$tcase$tmode
+      head -12 $O/timeline_$tcase${tmode:+_}$tmode${tlag:+_lag}$tlag.txt ;;
     pmcdefault)
       ( cd /tmp; export TMPDIR=/tmp; timeout -k 10 120 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU --output-format csv -d $O/pmc_default -o p -- python $GRAFT_REPO_ROOT/tools/probe_overlap.py > $O/pmc_default_schedule.txt 2>&1 ) || fail pmcdefault $?
       rm -rf $O/pmc_default; tail -2 $O/pmc_default_schedule.txt ;;

@@ -170,6 +170,7 @@ struct vrt_ctx {
     hipEvent_t ev_r[VRT_MAX_SETS] = {}, ev_t[VRT_MAX_SETS] = {}, ev_main = nullptr;
     bool ev_t_valid[VRT_MAX_SETS] = {};
     bool overlap_ready = false, overlap_failed = false;
+    unsigned mode_switches = 0;   // times the pipeline was drained to change its depth (ensure_overlap)
     bool main_dirty = true;   // work other than accumulate passes was queued on the main stream since the last overlapped launch
     unsigned pipe_seq = 0;    // overlapped launches so far
     int last_set = 0;         // copy (0 = the canonical buffers) the most recent render launch wrote
@@ -680,45 +681,71 @@ static int record(vrt_ctx* c, int kind, hipEvent_t* a, hipEvent_t* b) {
     return VRT_OK;
 }
 
-// Second copies, streams and events for overlapped launches; false (and never tried again) if they cannot be had.
-static bool ensure_overlap(vrt_ctx* c, int g) {   // g: samples of the launch that sets the pipeline up (the caller's habit: 1 or VRT_MAX_FUSED)
-    if (c->overlap_ready) return true;
-    if (c->overlap_failed) return false;
-    const size_t n = c->npix;
-    // How deep.  A launch lasts at least as long as its deepest path takes alone (about 0.2 ms at 8 bounces), whatever its
-    // size, and a workgroup slot its wave has left stays empty until the NEXT launch may start.  A launch of every slot can
-    // only be followed when it starts to drain (two in flight).  Launches of half the slots each follow one another at half
-    // that distance -- two run at full strength while a third drains and a fourth waits its turn.  Measured
-    // (profiles/r02_pipeline_depth.txt): 1080p x 4 samples +3.7 %, half of it +5 %, an eighth (one rank's rows of an 8-GPU
-    // run) +24 %; thirds and quarters of the slots are worse again; a 4K frame (33 M items a launch) loses 0-7 % and keeps
-    // the two-deep pipeline.
-    // VRT_DEEP_ITEMS: largest launch (pixels x fused samples) that gets the deep pipeline; VRT_STREAMS / VRT_GRID_DIV override.
-    const size_t deep_items = (size_t)c->knobs.deep_items;      // 12 M
+// How deep a launch of `g` samples wants the pipeline.  A launch lasts at least as long as its deepest path takes alone (about
+// 0.2 ms at 8 bounces), whatever its size, and a workgroup slot its wave has left stays empty until the NEXT launch may start.
+// A launch of every slot can only be followed when it starts to drain (two in flight).  Launches of half the slots each follow
+// one another at half that distance -- two run at full strength while a third drains and a fourth waits its turn.  Measured
+// (profiles/r02_pipeline_depth.txt): 1080p x 4 samples +3.7 %, half of it +5 %, an eighth (one rank's rows of an 8-GPU
+// run) +24 %; thirds and quarters of the slots are worse again; a 4K frame (33 M items a launch) loses 0-7 % and keeps
+// the two-deep pipeline.
+// Deeper still for the smallest launches -- one rank's rows of an 8-GPU split of 1080p are 1 M items: eight launches of a
+// quarter of the slots each (+7.5 % on those rows, +1 % on half a frame, nothing on a whole one).  Each render stream wants a
+// hardware queue of its own (two streams on one queue serialise), so only where the runtime was started with sixteen
+// (GPU_MAX_HW_QUEUES, which voxel_rt2_amd/_lib.py sets unless the user has).
+// VRT_DEEP_ITEMS / VRT_DEEPER_ITEMS (development build): largest launch (pixels x fused samples) of each kind; VRT_STREAMS /
+// VRT_GRID_DIV override.
+static void pipeline_mode_for(const vrt_ctx* c, int g, int* n_streams, int* grid_div) {
     const size_t items = (size_t)c->cfg.width * owned_rows(c) * (size_t)g;
-    const bool deep = items <= deep_items;
-    // Deeper still for the smallest frames -- one rank's rows of an 8-GPU split of 1080p are 1 M items a launch: eight launches
-    // of a quarter of the slots each (profiles/r02_pipeline_depth.txt: +7.5 % on those rows, +1 % on half a frame, nothing on a
-    // whole one).  Each render stream wants a hardware queue of its own (two streams on one queue serialise), so only where
-    // the runtime was started with sixteen (GPU_MAX_HW_QUEUES, which voxel_rt2_amd/_lib.py sets unless the user has).
-    const size_t deeper_items = (size_t)c->knobs.deeper_items;   // 2.5 M
-    const int hw_queues = c->knobs.hw_queues;
-    const bool deeper = deep && items <= deeper_items && hw_queues >= 16;
-    c->n_streams = deeper ? 8 : deep ? 4 : 2;
-    c->grid_div = deeper ? 4 : deep ? 2 : 1;
-    if (c->knobs.streams) c->n_streams = c->knobs.streams;
-    if (c->knobs.grid_div) c->grid_div = c->knobs.grid_div;
-    const int n_sets = c->n_streams + 1;
+    const bool deep = items <= (size_t)c->knobs.deep_items;                                         // 12 M
+    const bool deeper = deep && items <= (size_t)c->knobs.deeper_items && c->knobs.hw_queues >= 16;  // 2.5 M
+    *n_streams = deeper ? 8 : deep ? 4 : 2;
+    *grid_div = deeper ? 4 : deep ? 2 : 1;
+    if (c->knobs.streams) *n_streams = c->knobs.streams;
+    if (c->knobs.grid_div) *grid_div = c->knobs.grid_div;
+}
+// Streams, copies and events for a pipeline `want` launches deep (what a shallower one already has is kept).
+static bool grow_pipeline(vrt_ctx* c, int want) {
+    const size_t n = c->npix;
     bool ok = true;
-    for (int s = 0; s < n_sets - 1 && ok; s++)
+    for (int s = 0; s < want && ok; s++) {   // stream s, copy s + 1 (alt_*[s]) and, beyond the first, a pool scratch of its own
+        if (c->rstream[s]) continue;
         ok = dalloc(&c->alt_multi_d[s], n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->alt_spec_planes[s], n * VRT_MAX_FUSED) == hipSuccess &&
              dalloc(&c->alt_refl_planes[s], n * VRT_MAX_FUSED) == hipSuccess && dalloc(&c->alt_gb_pos[s], n) == hipSuccess &&
              dalloc(&c->alt_gb_mat[s], n) == hipSuccess;
-    for (int s = 0; s < c->n_streams && ok; s++) ok = hipStreamCreateWithFlags(&c->rstream[s], hipStreamNonBlocking) == hipSuccess;
-    for (int s = 0; s < c->n_streams - 1 && ok; s++)
-        ok = hipMalloc((void**)&c->alt_pool_scratch[s], pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks, c->render_blocks_d12)) == hipSuccess;
-    for (int s = 0; s < n_sets && ok; s++)
-        ok = hipEventCreateWithFlags(&c->ev_r[s], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&c->ev_t[s], hipEventDisableTiming) == hipSuccess;
+        if (ok && s > 0)
+            ok = hipMalloc((void**)&c->alt_pool_scratch[s - 1], pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks, c->render_blocks_d12)) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&c->rstream[s], hipStreamNonBlocking) == hipSuccess;   // (last: a stream that exists has everything)
+    }
+    for (int s = 0; s < want + 1 && ok; s++)
+        if (!c->ev_r[s])
+            ok = hipEventCreateWithFlags(&c->ev_r[s], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&c->ev_t[s], hipEventDisableTiming) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+// The pipeline for a launch of g samples; false (and never tried again) if its streams and copies cannot be had.  The depth
+// follows the launch: a context whose caller changes habit (one sample per call, then four) is drained once and goes on in
+// the other mode -- the set numbering and the gate distance of the two modes do not mix.
+static bool ensure_overlap(vrt_ctx* c, int g) {
+    if (c->overlap_failed) return false;
+    int ns = 0, gd = 0;
+    pipeline_mode_for(c, g, &ns, &gd);
+    if (c->overlap_ready) {
+        if (ns == c->n_streams && gd == c->grid_div) return true;
+        if (!grow_pipeline(c, ns)) return true;   // no memory for the other mode: this one goes on
+        if (sync_guarded(c, c->stream) != VRT_OK) return true;
+        for (int s = 0; s < VRT_MAX_STREAMS; s++) if (c->rstream[s]) (void)hipStreamSynchronize(c->rstream[s]);
+        if (sync_guarded(c, c->stream) != VRT_OK) return true;   // (the temporal passes behind those launches)
+        (void)hipGetLastError();
+        for (int s = 0; s < VRT_MAX_SETS; s++) c->ev_t_valid[s] = false;   // every pass has completed
+        c->n_streams = ns;
+        c->grid_div = gd;
+        c->mode_switches++;
+        return true;
+    }
+    bool ok = grow_pipeline(c, ns);
+    c->n_streams = ns;
+    c->grid_div = gd;
     ok = ok && hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) == hipSuccess;
     int can_wait = 0;
     bool want_gate = ok;
@@ -821,7 +848,8 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             if (c->d_pool_scratch) { HIP_TRY(hipFree(c->d_pool_scratch)); c->d_pool_scratch = nullptr; }
             HIP_TRY(hipMalloc((void**)&c->d_pool_scratch, pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks, c->render_blocks_d12)));
             if (c->overlap_ready) {  // the other render streams' scratch follows
-                for (int s = 0; s < c->n_streams - 1; s++) {
+                for (int s = 0; s < VRT_MAX_STREAMS - 1; s++) {   // (every stream the context has, whatever the depth in use)
+                    if (!c->rstream[s + 1]) continue;
                     if (c->alt_pool_scratch[s]) { HIP_TRY(hipFree(c->alt_pool_scratch[s])); c->alt_pool_scratch[s] = nullptr; }
                     HIP_TRY(hipMalloc((void**)&c->alt_pool_scratch[s], pool_scratch_bytes(c->cfg.grid_res, c->cfg.use_restir != 0, c->render_blocks, c->render_blocks_d12)));
                 }
@@ -1248,7 +1276,8 @@ int vrt_get_stats(vrt_ctx* c, vrt_stats* out) {
     HIP_TRY(hipMemcpy(&h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     c->stats.rays = h.rays; c->stats.dda_iters = h.iters; c->stats.occupancy_queries = h.queries;
     c->stats.closest_hits = h.closest_hits; c->stats.sky_lookups = h.sky_lookups;
-    c->stats.pipeline_flags = (c->overlap_ready ? 1u : 0u) | (c->drain_signal ? 2u : 0u) | ((uint32_t)c->gate_releases << 8) |
+    c->stats.pipeline_flags = (c->overlap_ready ? 1u : 0u) | (c->drain_signal ? 2u : 0u) | (((uint32_t)c->gate_releases & 0xFFFFu) << 8) |
+                              ((c->mode_switches < 255u ? c->mode_switches : 255u) << 24) |
                               (c->overlap_ready ? ((uint32_t)(c->n_streams >> 1) << 2) | ((uint32_t)c->grid_div << 5) : 0u);
     *out = c->stats;
     return VRT_OK;
