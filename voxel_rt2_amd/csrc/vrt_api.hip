@@ -28,12 +28,37 @@ using namespace vrt;
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#if defined(VRT_HOST_PROFILE)
+// Diagnostic build (tools/probe_host_cost.py): host time of every HIP_TRY call site, printed when the library is unloaded.
+#include <map>
+#include <algorithm>
+static double prof_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static std::map<std::string, std::pair<double, long>> g_prof;
+static struct ProfDump {
+    ~ProfDump() {
+        std::vector<std::pair<double, std::string>> rows;
+        for (auto& kv : g_prof) rows.push_back({kv.second.first, kv.first});
+        std::sort(rows.begin(), rows.end());
+        for (auto it = rows.rbegin(); it != rows.rend() && it - rows.rbegin() < 25; ++it)
+            fprintf(stderr, "[host] %9.1f ms %8ld calls %7.2f us  %s\n", it->first * 1e3, g_prof[it->second].second, it->first * 1e6 / (double)g_prof[it->second].second, it->second.substr(0, 110).c_str());
+    }
+} g_prof_dump;
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        const double t0_ = prof_now();                                                                  \
+        hipError_t e_ = (expr);                                                                         \
+        auto& p_ = g_prof[#expr]; p_.first += prof_now() - t0_; p_.second++;                            \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(VRT_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+#else
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \
         if (e_ != hipSuccess)                                                                           \
             return fail(VRT_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));               \
     } while (0)
+#endif
 
 struct EventPair { hipEvent_t a, b; int kind; };  // kind 0 render, 1 temporal, 2 gris
 
@@ -56,7 +81,7 @@ struct Knobs {
     long long deep_items = (long long)12 << 20, deeper_items = (long long)5 << 19;
     int streams = 0, grid_div = 0; // 0: decided from the frame size (ensure_overlap)
     bool drain_gate = true, fuse_restir = true, overlap_single = true;
-    int max_fused = VRT_MAX_FUSED, full_below = 2, chunk = 0, fail_launch = -1;
+    int max_fused = VRT_MAX_FUSED, full_below = 2, chunk = 0, fail_launch = -1, gate_extra = 0, time_every = 0;
 };
 static Knobs read_knobs() {
     Knobs k;
@@ -76,6 +101,8 @@ static Knobs read_knobs() {
     if (const char* e = getenv("VRT_FUSE")) { const int v = atoi(e); if (v >= 1 && v <= VRT_MAX_FUSED) k.max_fused = v; }
     if (const char* e = getenv("VRT_FUSE_RESTIR")) k.fuse_restir = atoi(e) != 0;
     if (const char* e = getenv("VRT_OVERLAP_SINGLE")) k.overlap_single = atoi(e) != 0;
+    if (const char* e = getenv("VRT_TIME_EVERY")) { const int v = atoi(e); if (v >= 1 && v <= 1024) k.time_every = v; }   // 0 (default): by launch size
+    if (const char* e = getenv("VRT_GATE_EXTRA")) { const int v = atoi(e); if (v >= 0 && v <= 4) k.gate_extra = v; }
     if (const char* e = getenv("VRT_FULL_BELOW")) { const int v = atoi(e); if (v >= 1 && v <= 3) k.full_below = v; }
     if (const char* e = getenv("VRT_CHUNK")) { const int v = atoi(e); if (v >= 64 && v <= 4096) k.chunk = v / 64 * 64; }
 #endif
@@ -170,6 +197,11 @@ struct vrt_ctx {
     hipEvent_t ev_r[VRT_MAX_SETS] = {}, ev_t[VRT_MAX_SETS] = {}, ev_main = nullptr;
     bool ev_t_valid[VRT_MAX_SETS] = {};
     bool overlap_ready = false, overlap_failed = false;
+    // Device time per kind of pass (0 render, 1 accumulation, 2 spatial reuse): every pass is counted, the ones that carry timers
+    // are summed (small launches: one in eight, accumulate_impl) and vrt_get_stats scales the sum to all of them.
+    double timed_ms[3] = {0.0, 0.0, 0.0};
+    uint32_t timed_n[3] = {0u, 0u, 0u}, passes_n[3] = {0u, 0u, 0u};
+    unsigned since_reset = 0;     // render launches since vrt_reset_stats: the first one carries timers
     unsigned mode_switches = 0;   // times the pipeline was drained to change its depth (ensure_overlap)
     bool main_dirty = true;   // work other than accumulate passes was queued on the main stream since the last overlapped launch
     unsigned pipe_seq = 0;    // overlapped launches so far
@@ -258,18 +290,26 @@ static bool gate_self_test(vrt_ctx* c) {
     return by_itself;
 }
 
-static void resolve_events(vrt_ctx* c) {
-    for (auto& ev : c->pending) {
-        float ms = 0.0f;
-        if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
-            if (ev.kind == 0) { c->stats.render_ms += ms; c->stats.render_launches++; }
-            else if (ev.kind == 1) { c->stats.temporal_ms += ms; c->stats.temporal_launches++; }
-            else { c->stats.gris_ms += ms; c->stats.gris_launches++; }
-        }
-        hipEventDestroy(ev.a);
-        hipEventDestroy(ev.b);
-    }
+static void account(vrt_ctx* c, const EventPair& ev) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) { c->timed_ms[ev.kind] += ms; c->timed_n[ev.kind]++; }
+    hipEventDestroy(ev.a);
+    hipEventDestroy(ev.b);
+}
+static void resolve_events(vrt_ctx* c) {   // waits for every launch timed so far
+    for (auto& ev : c->pending)
+        if (hipEventSynchronize(ev.b) == hipSuccess) account(c, ev);
+        else { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
     c->pending.clear();
+}
+// On the launch path: the timers of launches that HAVE completed are read and freed, nothing is waited for (a wait here would
+// empty the launch pipeline every hundred calls); a caller that never synchronises is held to 4096 outstanding timers.
+static void resolve_completed(vrt_ctx* c) {
+    if (c->pending.size() > 4096) { resolve_events(c); return; }
+    size_t done = 0;
+    while (done < c->pending.size() && hipEventQuery(c->pending[done].b) == hipSuccess) { account(c, c->pending[done]); done++; }
+    (void)hipGetLastError();   // (hipErrorNotReady is the expected answer at the first launch still running)
+    c->pending.erase(c->pending.begin(), c->pending.begin() + (long)done);
 }
 
 // The row ranges this context produces: one, or with vrt_set_row_stripes its stripes.
@@ -810,7 +850,13 @@ int vrt_accumulate(vrt_ctx* c, int n_samples) {
     if (!c->prepared) return fail(VRT_E_STATE, "vrt_prepare has not run since the last voxel upload");
     if (!c->have_cam) return fail(VRT_E_STATE, "vrt_set_camera has not been called");
     HIP_TRY(hipSetDevice(c->device));
+#if defined(VRT_HOST_PROFILE)
+    const double t_acc = prof_now();
     const int rc = accumulate_impl(c, n_samples);
+    { auto& p_ = g_prof["(the whole of accumulate_impl)"]; p_.first += prof_now() - t_acc; p_.second++; }
+#else
+    const int rc = accumulate_impl(c, n_samples);
+#endif
     if (rc != VRT_OK) abort_pipeline(c);
     else c->hdr_targets_committed = c->hdr_targets_written;
     return rc;
@@ -912,7 +958,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             // launches of half the slots the one before that (the signal carries the number + 1 of the latest launch draining)
             // -- unless the one before it took EVERY slot (a lone launch): then that one has to drain first
             // and never for a launch OLDER than the last one that took every slot: until that one drains there is no slot at all
-            const unsigned back = c->prev_launch_full ? 1u : (unsigned)c->grid_div;
+            const unsigned back = c->prev_launch_full ? 1u : (unsigned)(c->grid_div + c->knobs.gate_extra);
             unsigned target = c->launch_seq + 1u > back ? c->launch_seq + 1u - back : 0u;
             if (target < c->last_full_seq) target = c->last_full_seq;
             if (c->drain_signal && c->drain_signalled && target > 0u)
@@ -928,7 +974,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             HIP_TRY(hipMemcpyAsync(c->d_gb_mat, c->alt_gb_mat[a], c->npix * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
             c->last_set = 0;
         }
-        if (c->pending.size() > 192) resolve_events(c);
+        if (c->pending.size() > 192) resolve_completed(c);
         // (an asynchronous fetch may still be reading the HDR buffer this launch renders into; the passes below check theirs)
         if (!planes && wait_cbuf_readers(c, c->cidx) != VRT_OK) return VRT_E_DEVICE;
         FrameParams fp = make_frame_params(c);
@@ -952,10 +998,19 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         }
         out.gb_position = set ? c->alt_gb_pos[set - 1] : c->d_gb_pos; out.gb_mat = set ? c->alt_gb_mat[set - 1] : c->d_gb_mat;
         out.reservoir = restir ? c->d_res[0] - (size_t)(g - 1) * c->npix : nullptr;
-        hipEvent_t a, b;
-        if (record(c, 0, &a, &b) != VRT_OK) return VRT_E_DEVICE;
-        HIP_TRY(hipEventRecord(a, rs));
+        hipEvent_t a = nullptr, b = nullptr;
         const unsigned seq = c->launch_seq++;
+        // Timers (two events around each kernel, vrt_stats' device times) cost a small launch 3-12 % of its rate: the barrier packets
+        // they put around the kernel sit in the chain from one launch's drain to the next one's first wave.  Launches of up to
+        // 2.5 M work items -- a rank's rows of an 8-GPU split, the reference's one-sample calls -- carry them one time in eight.
+        const size_t launch_items = (size_t)c->cfg.width * owned_rows(c) * (size_t)g;
+        const unsigned every = c->knobs.time_every > 0 ? (unsigned)c->knobs.time_every : (launch_items <= (size_t)c->knobs.deeper_items ? 8u : 1u);
+        const bool timed = c->since_reset++ % every == 0u;   // this launch and its passes carry timers
+        c->passes_n[0]++;
+        if (timed) {
+            if (record(c, 0, &a, &b) != VRT_OK) return VRT_E_DEVICE;
+            HIP_TRY(hipEventRecord(a, rs));
+        }
         // test hook (tests/test_gpu_pipeline.py): launch number VRT_TEST_FAIL_LAUNCH (read at vrt_create) is reported as failed instead of queued
         if (c->knobs.fail_launch >= 0 && (unsigned)c->knobs.fail_launch == seq) return fail(VRT_E_DEVICE, "injected launch failure (VRT_TEST_FAIL_LAUNCH)");
         PrimaryRecord* prim = nullptr;  // fused samples share their camera rays through this table (vrt_pool.h)
@@ -972,7 +1027,7 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         c->drain_signalled = c->pooled && c->drain_signal != nullptr;
         c->prev_launch_full = blocks == all_blocks;
         if (c->prev_launch_full && c->pooled) c->last_full_seq = seq + 1u;
-        HIP_TRY(hipEventRecord(b, rs));
+        if (timed) HIP_TRY(hipEventRecord(b, rs));
         if (overlapped) {
             HIP_TRY(hipEventRecord(c->ev_r[set], rs));
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_r[set], 0));
@@ -994,10 +1049,13 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
                 gb.res_in = out.reservoir + off; gb.res_out = c->d_res[1];
                 gb.geo = c->d_gris_geo; gb.src = c->d_gris_src; gb.tst = c->d_gris_tst; gb.mats_x = c->d_mats_x;
                 int g0 = c->own0 - 2 < c->buf0 ? c->buf0 : c->own0 - 2, g1 = c->own1 + 2 > c->buf1 ? c->buf1 : c->own1 + 2;
-                if (record(c, 2, &a, &b) != VRT_OK) return VRT_E_DEVICE;
-                HIP_TRY(hipEventRecord(a, c->stream));
+                if (timed) {
+                    if (record(c, 2, &a, &b) != VRT_OK) return VRT_E_DEVICE;
+                    HIP_TRY(hipEventRecord(a, c->stream));
+                }
                 HIP_TRY(launch_gris(c->stream, c->cfg.grid_res, instr, fps, sc, gb, g0, g1));
-                HIP_TRY(hipEventRecord(b, c->stream));
+                c->passes_n[2]++;
+                if (timed) HIP_TRY(hipEventRecord(b, c->stream));
                 cd = c->d_color_d2;
                 cs = c->d_color_s2;
             }
@@ -1015,8 +1073,10 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             tb.prev_view = c->prev_view; tb.prev_proj = c->prev_proj;
             f3* const tile = (done + g >= n_samples && s == passes - 1) ? next_hdr_target(c) : nullptr;   // the pass that completes the call
             if (wait_cbuf_readers(c, ci ^ 1) != VRT_OK) return VRT_E_DEVICE;
-            if (record(c, 1, &a, &b) != VRT_OK) return VRT_E_DEVICE;
-            HIP_TRY(hipEventRecord(a, c->stream));
+            if (timed) {
+                if (record(c, 1, &a, &b) != VRT_OK) return VRT_E_DEVICE;
+                HIP_TRY(hipEventRecord(a, c->stream));
+            }
             tb.tile = tile;
             tb.tile_row0 = c->own0;
             if (c->stripe_rows) {   // one launch over the context's own rows, stripe after stripe (the kernel maps them: k_temporal)
@@ -1025,7 +1085,8 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
             } else {
                 HIP_TRY(launch_temporal(c->stream, fps, tb, c->own0, c->own1, restir ? 1 : g));
             }
-            HIP_TRY(hipEventRecord(b, c->stream));
+            if (timed) HIP_TRY(hipEventRecord(b, c->stream));
+            c->passes_n[1]++;
             hist ^= 1; ci ^= 1;   // pathtracer.py:1298-1303 copy loop == pointer swaps, once per accumulation pass
         }
         if (overlapped) {
@@ -1276,6 +1337,11 @@ int vrt_get_stats(vrt_ctx* c, vrt_stats* out) {
     HIP_TRY(hipMemcpy(&h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     c->stats.rays = h.rays; c->stats.dda_iters = h.iters; c->stats.occupancy_queries = h.queries;
     c->stats.closest_hits = h.closest_hits; c->stats.sky_lookups = h.sky_lookups;
+    {   // every pass counted, the timed ones' mean for all of them
+        auto scaled = [&](int k) { return c->timed_n[k] ? c->timed_ms[k] * ((double)c->passes_n[k] / (double)c->timed_n[k]) : 0.0; };
+        c->stats.render_ms = scaled(0); c->stats.temporal_ms = scaled(1); c->stats.gris_ms = scaled(2);
+        c->stats.render_launches = c->passes_n[0]; c->stats.temporal_launches = c->passes_n[1]; c->stats.gris_launches = c->passes_n[2];
+    }
     c->stats.pipeline_flags = (c->overlap_ready ? 1u : 0u) | (c->drain_signal ? 2u : 0u) | (((uint32_t)c->gate_releases & 0xFFFFu) << 8) |
                               ((c->mode_switches < 255u ? c->mode_switches : 255u) << 24) |
                               (c->overlap_ready ? ((uint32_t)(c->n_streams >> 1) << 2) | ((uint32_t)c->grid_div << 5) : 0u);
@@ -1290,6 +1356,8 @@ int vrt_reset_stats(vrt_ctx* c) {
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(Counters), c->stream));   // on the stream the counting launches follow on
     c->main_dirty = true;
     memset(&c->stats, 0, sizeof(c->stats));
+    for (int k = 0; k < 3; k++) { c->timed_ms[k] = 0.0; c->timed_n[k] = c->passes_n[k] = 0u; }
+    c->since_reset = 0u;
     return VRT_OK;
 }
 // Test hook: rows of arguments through single functions of the sky precompute (vrt_sky_kernels.hip, k_sky_probe).
