@@ -264,29 +264,27 @@ class ShardedRun:
             return s
 
         self.make_full_session = lambda: make_session(None)
-        # Row tiles: start from an equal split, then (untimed) let every rank measure its tile's device time and move the
-        # tile boundaries so that all ranks carry the same cost -- the sky rows of S1 cost a fraction of the floor rows.
+        # Row tiles: start from an equal split, then (untimed) let every rank measure what a step costs on its tile and move the
+        # tile boundaries so that all ranks carry the same cost -- the sky rows of S1 cost a fraction of the floor rows.  The cost
+        # is the step time with the launch pipeline in flight, as the timed steps run (a tile's isolated kernel time undervalues
+        # cheap rows: 365 sky rows "cost" what 80 floor rows do in isolation and a third more in the pipeline); three passes,
+        # each on the boundaries of the one before (tools/predict_scaling.py replays this on one GPU).
         self.bounds = split_rows(H, world)
         if balance and world > 1 and not self.stripes:
-            user_overlap = os.environ.get("VRT_OVERLAP")
-            os.environ["VRT_OVERLAP"] = "0"  # isolated launches while measuring (the library reads it when a context is created)
-            self.sess = make_session(self.bounds[rank])
-            for _ in range(2):
-                self.sess.accumulate(spp)
-                lib.vrt_reset_stats(C.c_void_p(self.sess._ctx))
-                self.sess.accumulate(spp)
-                st0 = self.sess.stats()
-                mine = torch.tensor([st0["render_ms"] + st0["temporal_ms"]], dtype=torch.float64, device=self.coll_dev)
+            for _ in range(3):
+                sess = make_session(self.bounds[rank])
+                for _w in range(8):
+                    sess.accumulate(spp)
+                sess.sync()
+                t0 = time.perf_counter()
+                for _w in range(24):
+                    sess.accumulate(spp)
+                sess.sync()
+                mine = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.coll_dev)
                 allc = [torch.zeros_like(mine) for _ in range(world)]
                 dist.all_gather(allc, mine)
                 self.bounds = parallel.rebalance_rows(self.bounds, [float(t.item()) for t in allc], H)
-                self.sess.close()
-                self.sess = make_session(self.bounds[rank])
-            self.sess.close()
-            if user_overlap is None:
-                os.environ.pop("VRT_OVERLAP", None)
-            else:
-                os.environ["VRT_OVERLAP"] = user_overlap
+                sess.close()
         self.sess = make_session(self.bounds[rank])
         self.steps_done = 0
         self.tiles_gathered = 0
