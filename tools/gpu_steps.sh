@@ -11,6 +11,7 @@
 #   trace:CASE      rocprofv3 --kernel-trace --stats of bench_scenes.py CASE (CASE = bench: the bench command, config 2)
 #   pmc:CASE        tools/pmc.sh CASE + summary
 #   timeline:CASE[:MODE[:LAG]]  launches and copies in time (tools/timeline.py)
+#   predict:CONFIG[:N,..]  predicted N-GPU step times (tools/predict_scaling.py)
 #   traffic         counters of every config -> profiles/traffic.json for this build;  present: present rates;  pmcdefault: the default schedule under --pmc
 #   diag:NAME:ARGS       tools/diag_regions.py ARGS (comma separated) with build_variants/libvrt_NAME.so (a -DVRT_DIAG_REGIONS build)
 #   variant:NAME:CASES   tools/bench_scenes.py CASES (comma separated) with build_variants/libvrt_NAME.so (built beforehand: tools/build_variant.sh)
@@ -70,8 +71,9 @@ for l in open('$O/variant_$vname.jsonl'):
       cp profiles/traffic.json $O/traffic.json
       rm -rf gpurun_out/${TAG}_pmc_* ;;
     present)   # the frame copied to the host after every step: blocking, asynchronous f32, asynchronous 8 bit
-      for mode in 1 async async8; do for lag in 1 2; do
-        [ $mode == 1 ] && [ $lag == 2 ] && continue
+      for mode in 1 async async8; do for lag in 1 2 3; do
+        [ $mode == 1 ] && [ $lag != 1 ] && continue
+        [ $mode == async ] && [ $lag == 3 ] && continue
         VRT_BENCH_STEPS=120 VRT_BENCH_FETCH_EACH=$mode VRT_BENCH_FETCH_LAG=$lag timeout -k 10 300 python tools/bench_scenes.py config2_s1 config4_dense 2>/dev/null | sed "s/_d8\"/_d8_present_${mode}_lag${lag}\"/; s/_1gpu\"/_1gpu_present_${mode}_lag${lag}\"/" >> $O/present.jsonl
       done; done; echo "present: $(grep -c name $O/present.jsonl)" ;;
     timeline)   # timeline:CASE[:MODE[:LAG]] -> kernel + copy trace of tools/bench_scenes.py CASE (MODE: VRT_BENCH_FETCH_EACH), digested by tools/timeline.py
@@ -80,6 +82,14 @@ for l in open('$O/variant_$vname.jsonl'):
         timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/tl_$tcase$tmode -o t -- python $GRAFT_REPO_ROOT/tools/bench_scenes.py $tcase > $O/tl_$tcase$tmode.jsonl 2> $O/tl_$tcase$tmode.err ) || fail timeline:$arg $?
       python tools/timeline.py $O/tl_$tcase$tmode > $O/timeline_$tcase${tmode:+_}$tmode${tlag:+_lag}$tlag.txt; rm -rf $O/tl_$tcase$tmode
       head -12 $O/timeline_$tcase${tmode:+_}$tmode${tlag:+_lag}$tlag.txt ;;
+    predict)   # predict:CONFIG[:N,N,...] -> tools/predict_scaling.py (bench.py --gpus N replayed rank by rank on this GPU)
+      IFS=: read -r pcfg pn <<< "$arg"
+      timeout -k 10 600 python tools/predict_scaling.py $pcfg ${pn//,/ } > $O/predict_$pcfg.jsonl 2> $O/predict_$pcfg.err || { tail -5 $O/predict_$pcfg.err; fail predict:$arg $?; }
+      python -c "
+import json
+for l in open('$O/predict_$pcfg.jsonl'):
+    d=json.loads(l)
+    if 'n_gpus' in d: print('  $pcfg N =', d['n_gpus'], 'equal', d['equal_speedup'], 'balanced', d['balanced_speedup'], {k: v['speedup'] for k, v in d.items() if k.startswith('stripes')})" ;;
     pmcdefault)
       ( cd /tmp; export TMPDIR=/tmp; timeout -k 10 120 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU --output-format csv -d $O/pmc_default -o p -- python $GRAFT_REPO_ROOT/tools/probe_overlap.py > $O/pmc_default_schedule.txt 2>&1 ) || fail pmcdefault $?
       rm -rf $O/pmc_default; tail -2 $O/pmc_default_schedule.txt ;;
