@@ -86,9 +86,9 @@ typedef struct vrt_camera {
 typedef struct vrt_stats {
     uint64_t path_samples;        /* pixels x accumulate passes since creation */
     uint64_t rays, dda_iters, occupancy_queries, closest_hits, sky_lookups; /* instrumented build only, else 0 */
-    double render_ms, temporal_ms, gris_ms;  /* summed device time of the kernels (hipEvent).  Launches of up to 2.5 M work items carry
-                                                their timers one time in eight (the events cost such a launch 3-12 % of its rate); the
-                                                sum is then the timed launches' mean times the number of all launches */
+    double render_ms, temporal_ms, gris_ms;  /* summed device time of the kernels (hipEvent).  Launches of up to 12 M work items (ReSTIR off)
+                                                carry their timers one time in eight (the events cost a step of 0.15-0.3 ms 3-25 % of its
+                                                rate); the sum is then the timed launches' mean times the number of all launches */
     uint32_t render_launches, temporal_launches, gris_launches;
     uint32_t pipeline_flags;      /* bit 0: launches of consecutive vrt_accumulate calls overlap; bit 1: the next launch's dispatch
                                      is held until the running one starts to drain (stream wait on a kernel-raised word; left out

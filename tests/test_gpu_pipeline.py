@@ -218,11 +218,12 @@ def test_pipeline_depth_follows_the_launch_size(monkeypatch):
     assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32))
 
 
-def test_pipeline_depth_of_the_shipped_library_at_720p(monkeypatch):
-    """The shipped library's own limits: at 1280x720 a one-sample call is a small launch (0.9 M items: eight deep), a four-sample
-    call a middle one (3.7 M: four deep).  (1, 4, 4, 1, 1, 4): three changes of depth, the frame that of isolated launches."""
+def test_pipeline_depth_of_the_shipped_library_at_900p(monkeypatch):
+    """The shipped library's own limits: at 1600x900 a one-sample call is a small launch (1.4 M items: eight deep), a four-sample
+    call a middle one (5.8 M, above the 4.5 M limit: four deep).  (1, 4, 4, 1, 1, 4): three changes of depth, the frame that of
+    isolated launches."""
     mat, rgb, params = scenes.scene_sunlit(0)
-    cfg = host.make_config(1280, 720, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=DEPTH, seed=5)
+    cfg = host.make_config(1600, 900, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=DEPTH, seed=5)
     frames = []
     for overlap in ("0", None):
         if overlap is not None:

@@ -143,6 +143,10 @@ def run(case):
 
 if __name__ == "__main__":
     only = sys.argv[1:]
+    for o in only:   # rows:A:B -> rows A..B of config 2 (S1, 1080p, 4 samples a step) as one rank's contiguous tile
+        if o.startswith("rows:"):
+            a, b = (int(x) for x in o.split(":")[1:3])
+            run(dict(name=f"config2_rows_{a}_{b}", scene="s1", W=1920, H=1080, depth=8, spp=4, steps=100, rows=(a, b)))
     for c in CASES:
         if not only or any(o in c["name"] for o in only):
             run(c)

@@ -78,7 +78,7 @@ struct Knobs {
     int hw_queues = 4;
     // development switches: the defaults below are what the shipped library always runs with
     int cull = -1, dense = -1;     // -1: decided from the scene (vrt_prepare)
-    long long deep_items = (long long)12 << 20, deeper_items = (long long)5 << 19;
+    long long deep_items = (long long)12 << 20, deeper_items = (long long)9 << 19;
     int streams = 0, grid_div = 0; // 0: decided from the frame size (ensure_overlap)
     bool drain_gate = true, fuse_restir = true, overlap_single = true;
     int max_fused = VRT_MAX_FUSED, full_below = 2, chunk = 0, fail_launch = -1, gate_extra = 0, time_every = 0;
@@ -728,8 +728,9 @@ static int record(vrt_ctx* c, int kind, hipEvent_t* a, hipEvent_t* b) {
 // (profiles/r02_pipeline_depth.txt): 1080p x 4 samples +3.7 %, half of it +5 %, an eighth (one rank's rows of an 8-GPU
 // run) +24 %; thirds and quarters of the slots are worse again; a 4K frame (33 M items a launch) loses 0-7 % and keeps
 // the two-deep pipeline.
-// Deeper still for the smallest launches -- one rank's rows of an 8-GPU split of 1080p are 1 M items: eight launches of a
-// quarter of the slots each (+7.5 % on those rows, +1 % on half a frame, nothing on a whole one).  Each render stream wants a
+// Deeper still for the smaller launches -- one rank's rows of an 8-GPU split of 1080p are 1 M items: eight launches of a
+// quarter of the slots each (+7.5 % on those rows; with the timers thinned out, below: +2 % on half a frame of 4.1 M items,
+// +17 % on its cheap upper 480 rows, -2 % on a whole frame, -9 % on the sun-lit one: the limit is 4.5 M items).  Each render stream wants a
 // hardware queue of its own (two streams on one queue serialise), so only where the runtime was started with sixteen
 // (GPU_MAX_HW_QUEUES, which voxel_rt2_amd/_lib.py sets unless the user has).
 // VRT_DEEP_ITEMS / VRT_DEEPER_ITEMS (development build): largest launch (pixels x fused samples) of each kind; VRT_STREAMS /
@@ -737,7 +738,7 @@ static int record(vrt_ctx* c, int kind, hipEvent_t* a, hipEvent_t* b) {
 static void pipeline_mode_for(const vrt_ctx* c, int g, int* n_streams, int* grid_div) {
     const size_t items = (size_t)c->cfg.width * owned_rows(c) * (size_t)g;
     const bool deep = items <= (size_t)c->knobs.deep_items;                                         // 12 M
-    const bool deeper = deep && items <= (size_t)c->knobs.deeper_items && c->knobs.hw_queues >= 16;  // 2.5 M
+    const bool deeper = deep && items <= (size_t)c->knobs.deeper_items && c->knobs.hw_queues >= 16;  // 4.5 M
     *n_streams = deeper ? 8 : deep ? 4 : 2;
     *grid_div = deeper ? 4 : deep ? 2 : 1;
     if (c->knobs.streams) *n_streams = c->knobs.streams;
@@ -1000,11 +1001,13 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         out.reservoir = restir ? c->d_res[0] - (size_t)(g - 1) * c->npix : nullptr;
         hipEvent_t a = nullptr, b = nullptr;
         const unsigned seq = c->launch_seq++;
-        // Timers (two events around each kernel, vrt_stats' device times) cost a small launch 3-12 % of its rate: the barrier packets
-        // they put around the kernel sit in the chain from one launch's drain to the next one's first wave.  Launches of up to
-        // 2.5 M work items -- a rank's rows of an 8-GPU split, the reference's one-sample calls -- carry them one time in eight.
+        // Timers (two events around each kernel, vrt_stats' device times) cost a short step its rate: the barrier packets they put
+        // around the kernel sit in the chain from one launch's drain to the next one's first wave -- a fixed 30-40 us of a step,
+        // 3-25 % of the steps of 0.15-0.3 ms that a rank's rows of an 8-GPU split or the reference's one-sample calls take, nothing
+        // of a 1 ms step.  What a step will take is not known here, its size is: launches of the deep pipelines (up to 12 M work
+        // items, ReSTIR off) carry timers one time in eight; vrt_get_stats scales the timed launches' sum to all of them.
         const size_t launch_items = (size_t)c->cfg.width * owned_rows(c) * (size_t)g;
-        const unsigned every = c->knobs.time_every > 0 ? (unsigned)c->knobs.time_every : (launch_items <= (size_t)c->knobs.deeper_items ? 8u : 1u);
+        const unsigned every = c->knobs.time_every > 0 ? (unsigned)c->knobs.time_every : ((!restir && launch_items <= (size_t)c->knobs.deep_items) ? 8u : 1u);
         const bool timed = c->since_reset++ % every == 0u;   // this launch and its passes carry timers
         c->passes_n[0]++;
         if (timed) {
