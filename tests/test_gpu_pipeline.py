@@ -243,6 +243,28 @@ def test_pipeline_depth_of_the_shipped_library_at_900p(monkeypatch):
     assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32))
 
 
+def test_stats_count_every_launch_and_scale_the_timed_ones():
+    """Launches of the deep pipelines carry their timers one time in eight (include/vrt_api.h, vrt_stats): the counts are of ALL
+    launches and passes, the times the timed launches' mean times those counts -- after a reset the first launch is a timed one,
+    so a window of fewer than eight launches still has a time."""
+    mat, rgb, params = scenes.scene_sunlit(0)
+    cfg = host.make_config(W, H, voxel_edges=params["voxel_edges"], exposure=params["exposure"], max_depth=DEPTH, seed=5)
+    s = _session(cfg, mat, rgb, params)
+    for _ in range(20):
+        s.accumulate(4)
+    st = s.stats()
+    assert st["render_launches"] == 20 and st["temporal_launches"] == 20 and st["path_samples"] == 20 * 4 * W * H, st
+    per_launch = st["render_ms"] / st["render_launches"]
+    assert 0.01 < per_launch < 5.0 and st["temporal_ms"] > 0.0, st
+    _lib.load().vrt_reset_stats(C.c_void_p(s._ctx))
+    for _ in range(3):
+        s.accumulate(4)
+    st = s.stats()
+    assert st["render_launches"] == 3 and 0.01 < st["render_ms"] / 3 < 5.0, st
+    assert 0.3 < (st["render_ms"] / 3) / per_launch < 3.0, (st, per_launch)   # the same kind of launch: the same time, roughly
+    s.close()
+
+
 def test_single_sample_calls_with_a_new_jitter_each():
     """The reference's own loop shape (scene.py:177, 233-262: samples_per_frame = 1, set_proj_mat draws a new jitter every frame,
     accumulate, copy_prev_matrices): twelve one-sample calls, a new jitter index before each, pipelined like fused launches

@@ -735,10 +735,12 @@ static int record(vrt_ctx* c, int kind, hipEvent_t* a, hipEvent_t* b) {
 // (GPU_MAX_HW_QUEUES, which voxel_rt2_amd/_lib.py sets unless the user has).
 // VRT_DEEP_ITEMS / VRT_DEEPER_ITEMS (development build): largest launch (pixels x fused samples) of each kind; VRT_STREAMS /
 // VRT_GRID_DIV override.
-static void pipeline_mode_for(const vrt_ctx* c, int g, int* n_streams, int* grid_div) {
+static void pipeline_mode_for(const vrt_ctx* c, int g, bool heavy, int* n_streams, int* grid_div) {
+    // (heavy: the dense-grid kernel -- six rays a path instead of two: an item is about twice the work, a rank's 4.1 M items of an
+    // 8-way split of a dense 4K frame lose 10 % in the eight-deep pipeline that the same number of S1's items gain 2-17 % from)
     const size_t items = (size_t)c->cfg.width * owned_rows(c) * (size_t)g;
     const bool deep = items <= (size_t)c->knobs.deep_items;                                         // 12 M
-    const bool deeper = deep && items <= (size_t)c->knobs.deeper_items && c->knobs.hw_queues >= 16;  // 4.5 M
+    const bool deeper = deep && items * (heavy ? 2u : 1u) <= (size_t)c->knobs.deeper_items && c->knobs.hw_queues >= 16;  // 4.5 M
     *n_streams = deeper ? 8 : deep ? 4 : 2;
     *grid_div = deeper ? 4 : deep ? 2 : 1;
     if (c->knobs.streams) *n_streams = c->knobs.streams;
@@ -767,10 +769,10 @@ static bool grow_pipeline(vrt_ctx* c, int want) {
 // The pipeline for a launch of g samples; false (and never tried again) if its streams and copies cannot be had.  The depth
 // follows the launch: a context whose caller changes habit (one sample per call, then four) is drained once and goes on in
 // the other mode -- the set numbering and the gate distance of the two modes do not mix.
-static bool ensure_overlap(vrt_ctx* c, int g) {
+static bool ensure_overlap(vrt_ctx* c, int g, bool heavy) {
     if (c->overlap_failed) return false;
     int ns = 0, gd = 0;
-    pipeline_mode_for(c, g, &ns, &gd);
+    pipeline_mode_for(c, g, heavy, &ns, &gd);
     if (c->overlap_ready) {
         if (ns == c->n_streams && gd == c->grid_div) return true;
         if (!grow_pipeline(c, ns)) return true;   // no memory for the other mode: this one goes on
@@ -929,7 +931,8 @@ static int accumulate_impl(vrt_ctx* c, int n_samples) {
         if ((g > 1 || want_overlap) && !c->d_multi_d) {
             if (dalloc(&c->d_multi_d, c->npix * VRT_MAX_FUSED) != hipSuccess) { (void)hipGetLastError(); c->d_multi_d = nullptr; g = 1; want_overlap = false; }  // no memory: one launch per sample
         }
-        const bool overlapped = want_overlap && ensure_overlap(c, g);
+        const bool heavy = c->pooled && c->render_blocks_d12 > 0 && pool_uses_dense12(c->cfg.grid_res, restir, c->dense_grid, make_frame_params(c));
+        const bool overlapped = want_overlap && ensure_overlap(c, g, heavy);
         const bool planes = g > 1 || overlapped;   // the launch writes colour planes of its own, not the HDR buffer
         const int set = overlapped ? (int)(c->pipe_seq % (unsigned)(c->n_streams + 1)) : 0;
         const int lane_of = (int)(c->pipe_seq % (unsigned)c->n_streams);  // which render stream (and pool scratch): consecutive launches take turns
