@@ -267,11 +267,12 @@ class ShardedRun:
         # Row tiles: start from an equal split, then (untimed) let every rank measure what a step costs on its tile and move the
         # tile boundaries so that all ranks carry the same cost -- the sky rows of S1 cost a fraction of the floor rows.  The cost
         # is the step time with the launch pipeline in flight, as the timed steps run (a tile's isolated kernel time undervalues
-        # cheap rows: 365 sky rows "cost" what 80 floor rows do in isolation and a third more in the pipeline); three passes,
+        # cheap rows: 365 sky rows "cost" what 80 floor rows do in isolation and a third more in the pipeline); five passes (a step has
+        # a part that no row count removes, which the per-row model of rebalance_rows takes four or five passes to work around),
         # each on the boundaries of the one before (tools/predict_scaling.py replays this on one GPU).
         self.bounds = split_rows(H, world)
         if balance and world > 1 and not self.stripes:
-            for _ in range(3):
+            for _ in range(5):
                 sess = make_session(self.bounds[rank])
                 for _w in range(8):
                     sess.accumulate(spp)

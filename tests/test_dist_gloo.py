@@ -66,6 +66,30 @@ def test_sharded_frame_equals_full_frame(tmp_path, world, restir):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+def test_rebalance_rows_equalises_a_step_time_with_a_fixed_part():
+    """bench.py's balancing passes (ShardedRun): every rank reports what a step costs on its rows, the boundaries move, again.
+    A cost model like the measured one -- a per-row cost that varies fivefold down the frame (S1's sky rows against its horizon
+    rows) plus a fixed part per step that no row count removes -- must come out within a few per cent after bench.py's five passes, with the
+    tiles still covering the frame once and none below the minimum."""
+    from voxel_rt2_amd import parallel
+    H, fixed = 1080, 0.03
+    row_cost = np.where(np.arange(H) > 700, 0.0002, 0.001) + 0.0004 * np.exp(-((np.arange(H) - 520) / 60.0) ** 2)
+    for world in (2, 3, 4, 8):
+        bounds = parallel.split_rows(H, world)
+        cost = lambda b: [fixed + float(row_cost[a:e].sum()) for a, e in b]
+        first = max(cost(bounds)) / min(cost(bounds))
+        for _ in range(5):
+            bounds = parallel.rebalance_rows(bounds, cost(bounds), H)
+            assert bounds[0][0] == 0 and bounds[-1][1] == H and all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1))
+            assert all(e - a >= 8 for a, e in bounds)
+        c = cost(bounds)
+        assert max(c) / min(c) < min(1.08, first), (world, bounds, c)
+    assert parallel.rebalance_rows([(0, 1080)], [1.0], 1080) == [(0, 1080)]
+    # ranks that report nothing useful (zero cost) still get their minimum of rows
+    b = parallel.rebalance_rows(parallel.split_rows(64, 4), [0.0, 0.0, 1.0, 0.0], 64)
+    assert b[0][0] == 0 and b[-1][1] == 64 and all(e - a >= 8 for a, e in b)
+
+
 def test_split_rows_covers_frame():
     from voxel_rt2_amd import parallel
     for h in (1080, 2160, 50, 7):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What `bench.py --gpus N` does at N = 2, 4, 8, replayed on ONE GPU rank by rank: the equal split, the three balancing passes
+"""What `bench.py --gpus N` does at N = 2, 4, 8, replayed on ONE GPU rank by rank: the equal split, the five balancing passes
 of ShardedRun (each tile's step time with the pipeline in flight, parallel.rebalance_rows), then every balanced tile
 timed alone with the pipeline in flight.  The slowest tile's step time is the predicted step time of the N-GPU run (the gather
 overlaps the next step); against the whole frame's step time measured in the same process.  Also: interleaved stripes, the rank
@@ -60,7 +60,7 @@ def main():
         bounds = parallel.split_rows(cf["H"], world)
         equal = [step_ms(cf, b, None, world)[0] for b in bounds]
         short = dict(cf, steps=24)
-        for _ in range(3):   # ShardedRun's balancing passes: the pipelined step time of every tile, boundaries moved, again
+        for _ in range(5):   # ShardedRun's balancing passes: the pipelined step time of every tile, boundaries moved, again
             bounds = parallel.rebalance_rows(bounds, [step_ms(short, b, None, world)[0] for b in bounds], cf["H"])
         bal = [step_ms(cf, b, None, world)[0] for b in bounds]
         out = dict(config=name, n_gpus=world, whole_frame_ms=round(full, 4),
