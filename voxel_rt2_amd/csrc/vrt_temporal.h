@@ -86,6 +86,19 @@ VRT_DEV f3 bilinear_color(const FrameParams& fp, const f3* buf, f2 uv) {
     f3 tl = scrub(buf[clamped_index(fp, ix, iy + 1)]), tr = scrub(buf[clamped_index(fp, ix + 1, iy + 1)]);
     return lerp3(lerp3(bl, br, fx), lerp3(tl, tr, fx), fy);
 }
+// the same fetch from two buffers at one texcoord (a sample's diffuse and specular planes): the eight taps fetched together
+VRT_DEV void bilinear_color2(const FrameParams& fp, const f3* buf_a, const f3* buf_b, f2 uv, f3& out_a, f3& out_b) {
+    int rx, ry;
+    render_res(fp, rx, ry);
+    float fcx = uv.x * (float)rx - 0.5f, fcy = uv.y * (float)ry - 0.5f;
+    int ix = dm_f2i(fcx), iy = dm_f2i(fcy);
+    float fx = frac1(fcx), fy = frac1(fcy);
+    const int i0 = clamped_index(fp, ix, iy), i1 = clamped_index(fp, ix + 1, iy), i2 = clamped_index(fp, ix, iy + 1), i3 = clamped_index(fp, ix + 1, iy + 1);
+    const f3 a0 = buf_a[i0], a1 = buf_a[i1], a2 = buf_a[i2], a3 = buf_a[i3];
+    const f3 b0 = buf_b[i0], b1 = buf_b[i1], b2 = buf_b[i2], b3 = buf_b[i3];
+    out_a = lerp3(lerp3(scrub(a0), scrub(a1), fx), lerp3(scrub(a2), scrub(a3), fx), fy);
+    out_b = lerp3(lerp3(scrub(b0), scrub(b1), fx), lerp3(scrub(b2), scrub(b3), fx), fy);
+}
 VRT_DEV f3 reproject(const FrameParams& fp, const TemporalBuffers& tb, f3 wp) {  // pathtracer.py:993-1000
     f4 p = mul4(tb.prev_proj, mul4(tb.prev_view, mk4(wp.x, wp.y, wp.z, 1.0f)));
     return mk3(p.x / p.w, p.y / p.w, p.z / p.w) * 0.5f + 0.5f;
@@ -167,15 +180,23 @@ VRT_DEV void temporal_pixel(const FrameParams& fp, const TemporalBuffers& tb, in
     const int last = (n_samples - 1) * tb.sample_stride;  // plane of the last sample
 
     // prepass: reflection-depth average over the valid taps of a 4x4 window (:1040-1066)
+    // (the 16 taps are fetched before any is looked at -- a tap outside the window fetches the pixel's own word, which is not
+    // used: fetched one by one, each behind the test of the one before, the loop was 16 memory round trips in a row, and beside a
+    // render launch this pass runs at one wave per SIMD with nothing to hide them behind; the sums run in the reference's order)
     float rsum = 0.0f, rcount = 0.0f;
-    for (int x = -1; x < 3; x++)
-        for (int y = -1; y < 3; y++) {
-            int tx = u + x, ty = v + y;
-            if (tx < 0 || ty < 0 || tx > rx - 1 || ty > ry - 1) continue;
-            if (ty < fp.row0 || ty >= fp.row1) continue;  // beyond the shard's halo (reflection depth is unused there)
-            float rd = tb.gb_refl_raw[last + (ty - fp.row0) * fp.W + tx];
-            if (rd != 0.0f) { rcount += 1.0f; rsum += rd; }
+    {
+        float rd[16];
+        bool in[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int tx = u + (t >> 2) - 1, ty = v + (t & 3) - 1;
+            in[t] = !(tx < 0 || ty < 0 || tx > rx - 1 || ty > ry - 1) && !(ty < fp.row0 || ty >= fp.row1);  // (beyond the shard's halo: reflection depth is unused there)
+            rd[t] = tb.gb_refl_raw[last + (in[t] ? (ty - fp.row0) * fp.W + tx : idx)];
         }
+#pragma unroll
+        for (int t = 0; t < 16; t++)
+            if (in[t] && rd[t] != 0.0f) { rcount += 1.0f; rsum += rd[t]; }
+    }
     const float refl_depth = (rcount > 0.01f) ? rsum / rcount : 0.0f;
     tb.gb_refl_filtered[idx] = refl_depth;
 
@@ -193,8 +214,8 @@ VRT_DEV void temporal_pixel(const FrameParams& fp, const TemporalBuffers& tb, in
         hd = tb.hist_d_in[idx];
         hs = tb.hist_s_in[idx];
         for (int k = 0; k < n_samples; k++) {
-            const f3 cur_d = bilinear_color(fp, tb.color_d + k * tb.sample_stride, tc);
-            const f3 cur_s = bilinear_color(fp, tb.color_s + k * tb.sample_stride, tc);
+            f3 cur_d, cur_s;
+            bilinear_color2(fp, tb.color_d + k * tb.sample_stride, tb.color_s + k * tb.sample_stride, tc, cur_d, cur_s);
             blend_history(fp, 1.0f, hd, cur_d);
             blend_history(fp, 1.0f, hs, cur_s);
         }
