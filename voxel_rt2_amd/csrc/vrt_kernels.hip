@@ -864,16 +864,22 @@ __global__ void k_mat_derived(const float* mats, float* mats_x) {
 #ifndef VRT_TEMPORAL_HALF_VGPRS
 #define VRT_TEMPORAL_HALF_VGPRS 48   // the attribute counts half of the unified register file
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(VRT_TEMPORAL_HALF_VGPRS))) void k_temporal(FrameParams fp, TemporalBuffers tb, int r0, int r1, int n_samples) {
+// Workgroups of VRT_TEMPORAL_ROWS waves (one image row each).  One: beside a render launch a SIMD has room for one wave of this
+// kernel, and a workgroup of four waits until all four SIMDs of a CU have theirs free at once (one-wave workgroups: the frame's
+// upper rows as a rank's tile +4 %, one-sample calls +2 %, the whole frame unchanged; profiles/r04_zj_*).
+#ifndef VRT_TEMPORAL_ROWS
+#define VRT_TEMPORAL_ROWS 1
+#endif
+__global__ __launch_bounds__(64 * VRT_TEMPORAL_ROWS) __attribute__((amdgpu_num_vgpr(VRT_TEMPORAL_HALF_VGPRS))) void k_temporal(FrameParams fp, TemporalBuffers tb, int r0, int r1, int n_samples) {
     const int u = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int v = r0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int v = r0 + blockIdx.y * VRT_TEMPORAL_ROWS + (threadIdx.x >> 6);
     if (u < fp.W && v < r1) temporal_pixel(fp, tb, u, v, n_samples);
 }
 // the same pass over a striped context's OWN rows (vrt_set_row_stripes): n_own of them, stripe after stripe, in ONE launch (a launch
 // per stripe put 17 dispatches on the context's stream per step of an eighth of 1080p in 8-row stripes: 0.66 ms a step for 0.19)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(VRT_TEMPORAL_HALF_VGPRS))) void k_temporal_stripes(FrameParams fp, TemporalBuffers tb, int n_own, int n_samples) {
+__global__ __launch_bounds__(64 * VRT_TEMPORAL_ROWS) __attribute__((amdgpu_num_vgpr(VRT_TEMPORAL_HALF_VGPRS))) void k_temporal_stripes(FrameParams fp, TemporalBuffers tb, int n_own, int n_samples) {
     const int u = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int k = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int k = blockIdx.y * VRT_TEMPORAL_ROWS + (threadIdx.x >> 6);
     if (k >= n_own) return;
     const int v = (k / fp.stripe_rows) * fp.stripe_period + fp.stripe_first + k % fp.stripe_rows;
     if (u < fp.W && v < fp.H) temporal_pixel<true>(fp, tb, u, v, n_samples);
@@ -1060,7 +1066,7 @@ hipError_t launch_gris(hipStream_t st, int grid_res, bool instr, const FramePara
     return hipSuccess;
 }
 hipError_t launch_temporal(hipStream_t st, const FrameParams& fp, const TemporalBuffers& tb, int r0, int r1, int n_samples) {
-    dim3 g((fp.W + 63) / 64, (r1 - r0 + 3) / 4), b(256);
+    dim3 g((fp.W + 63) / 64, (r1 - r0 + VRT_TEMPORAL_ROWS - 1) / VRT_TEMPORAL_ROWS), b(64 * VRT_TEMPORAL_ROWS);
     if (fp.stripe_period) hipLaunchKernelGGL(k_temporal_stripes, g, b, 0, st, fp, tb, r1 - r0, n_samples);   // (r0 = 0, r1 = the context's own rows)
     else hipLaunchKernelGGL(k_temporal, g, b, 0, st, fp, tb, r0, r1, n_samples);
     VRT_LAUNCH_CHECK();
