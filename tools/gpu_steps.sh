@@ -19,7 +19,7 @@ set -o pipefail
 TAG=$1; shift
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-fail() { echo "$1 FAILED rc=$2"; exit $2; }
+fail() { local rc=${2:-1}; [ "$rc" == 0 ] && rc=1; echo "$1 FAILED rc=$rc"; exit $rc; }   # (never 0: a later step must not start)
 for step in "$@"; do
   name=${step%%:*}; arg=${step#*:}; [ "$arg" == "$step" ] && arg=""
   case $name in
@@ -27,20 +27,20 @@ for step in "$@"; do
       timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || fail smoke $?
       tail -1 $O/smoke.log ;;
     tests)
-      if [ -n "$arg" ]; then timeout -k 10 1000 python -m pytest tests/ -x -q -m gpu -k "$arg" > $O/pytest_gpu.log 2>&1 || { tail -30 $O/pytest_gpu.log; fail tests $?; }
-      else timeout -k 10 1000 python -m pytest tests/ -x -q -m gpu > $O/pytest_gpu.log 2>&1 || { tail -30 $O/pytest_gpu.log; fail tests $?; }; fi
+      if [ -n "$arg" ]; then timeout -k 10 1000 python -m pytest tests/ -x -q -m gpu -k "$arg" > $O/pytest_gpu.log 2>&1 || { rc=$?; tail -30 $O/pytest_gpu.log; fail tests $rc; }
+      else timeout -k 10 1000 python -m pytest tests/ -x -q -m gpu > $O/pytest_gpu.log 2>&1 || { rc=$?; tail -30 $O/pytest_gpu.log; fail tests $rc; }; fi
       tail -1 $O/pytest_gpu.log ;;
     bench)
-      timeout -k 10 600 python bench.py $arg > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.err; fail bench $?; }
+      timeout -k 10 600 python bench.py $arg > $O/bench.json 2> $O/bench.err || { rc=$?; tail -5 $O/bench.err; fail bench $rc; }
       python tools/bench_digest.py $O/bench.json ;;
     scenes)
-      timeout -k 10 900 python tools/bench_scenes.py ${arg//,/ } > $O/scenes${arg:+_}${arg//,/_}.jsonl 2> $O/scenes.err || { tail -5 $O/scenes.err; fail scenes $?; }
+      timeout -k 10 900 python tools/bench_scenes.py ${arg//,/ } > $O/scenes${arg:+_}${arg//,/_}.jsonl 2> $O/scenes.err || { rc=$?; tail -5 $O/scenes.err; fail scenes $rc; }
       python -c "
 import json,sys
 for l in open('$O/scenes${arg:+_}${arg//,/_}.jsonl'):
     d=json.loads(l); print(' ', d.get('name'), d.get('mpaths_per_s'), {k:v for k,v in d.items() if k.endswith('_ms')})" ;;
     refidx)
-      for c in 4 5; do timeout -k 10 600 python tools/ref_indexing_diff.py --backend gpu --config $c > $O/refidx_config$c.json 2> $O/refidx.err || { tail -5 $O/refidx.err; fail refidx $?; }; cat $O/refidx_config$c.json; done ;;
+      for c in 4 5; do timeout -k 10 600 python tools/ref_indexing_diff.py --backend gpu --config $c > $O/refidx_config$c.json 2> $O/refidx.err || { rc=$?; tail -5 $O/refidx.err; fail refidx $rc; }; cat $O/refidx_config$c.json; done ;;
     trace)
       ( cd /tmp; export TMPDIR=/tmp
         if [ "$arg" == "bench" ]; then timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_bench -o t -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-secondary > $O/bench_under_rocprof.json 2> $O/trace_bench.err
@@ -53,7 +53,7 @@ for l in open('$O/scenes${arg:+_}${arg//,/_}.jsonl'):
       echo "pmc $arg: $(grep -c mean $O/pmc_$arg.txt) rows" ;;
     variant)
       IFS=: read -r vname vcases <<< "$arg"
-      VRT_LIB_PATH=$GRAFT_REPO_ROOT/build_variants/libvrt_$vname.so timeout -k 10 600 python tools/bench_scenes.py ${vcases//,/ } > $O/variant_$vname.jsonl 2> $O/variant_$vname.err || { tail -5 $O/variant_$vname.err; fail variant:$vname $?; }
+      VRT_LIB_PATH=$GRAFT_REPO_ROOT/build_variants/libvrt_$vname.so timeout -k 10 600 python tools/bench_scenes.py ${vcases//,/ } > $O/variant_$vname.jsonl 2> $O/variant_$vname.err || { rc=$?; tail -5 $O/variant_$vname.err; fail variant:$vname $rc; }
       python -c "
 import json
 for l in open('$O/variant_$vname.jsonl'):
@@ -84,7 +84,7 @@ for l in open('$O/variant_$vname.jsonl'):
       head -12 $O/timeline_$tcase${tmode:+_}$tmode${tlag:+_lag}$tlag.txt ;;
     predict)   # predict:CONFIG[:N,N,...] -> tools/predict_scaling.py (bench.py --gpus N replayed rank by rank on this GPU)
       IFS=: read -r pcfg pn <<< "$arg"
-      timeout -k 10 600 python tools/predict_scaling.py $pcfg ${pn//,/ } > $O/predict_$pcfg.jsonl 2> $O/predict_$pcfg.err || { tail -5 $O/predict_$pcfg.err; fail predict:$arg $?; }
+      timeout -k 10 600 python tools/predict_scaling.py $pcfg ${pn//,/ } > $O/predict_$pcfg.jsonl 2> $O/predict_$pcfg.err || { rc=$?; tail -5 $O/predict_$pcfg.err; fail predict:$arg $rc; }
       python -c "
 import json
 for l in open('$O/predict_$pcfg.jsonl'):
@@ -95,7 +95,7 @@ for l in open('$O/predict_$pcfg.jsonl'):
       rm -rf $O/pmc_default; tail -2 $O/pmc_default_schedule.txt ;;
     diag)   # diag:NAME:ARGS -> tools/diag_regions.py ARGS with build_variants/libvrt_NAME.so (a -DVRT_DIAG_REGIONS build)
       IFS=: read -r vname dargs <<< "$arg"
-      VRT_LIB_PATH=$GRAFT_REPO_ROOT/build_variants/libvrt_$vname.so timeout -k 10 600 python tools/diag_regions.py ${dargs//,/ } > $O/diag_$vname.txt 2> $O/diag_$vname.err || { tail -5 $O/diag_$vname.err; fail diag:$vname $?; }
+      VRT_LIB_PATH=$GRAFT_REPO_ROOT/build_variants/libvrt_$vname.so timeout -k 10 600 python tools/diag_regions.py ${dargs//,/ } > $O/diag_$vname.txt 2> $O/diag_$vname.err || { rc=$?; tail -5 $O/diag_$vname.err; fail diag:$vname $rc; }
       cat $O/diag_$vname.txt ;;
     *) echo "unknown step $step"; exit 64 ;;
   esac
